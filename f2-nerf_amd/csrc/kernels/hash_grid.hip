@@ -1,0 +1,302 @@
+// hash_grid.hip -- multi-resolution hash-grid encode, forward and backward.
+//
+// Replaces Hash3DAnchoredForwardKernel / Hash3DAnchoredBackwardKernel and the dtype glue around
+// them (reference src/hash_3d_anchored.cu:60-218) plus the contraction of
+// Hash3DAnchored::query (src/hash_3d_anchored.cpp:79-82).
+//
+// Launch shape: grid = (ceil(n/256), L), block = 256 (4 wavefronts).  blockIdx.y = level, so a
+// workgroup is level-uniform: mul/bias/primes/level base live in SGPRs (scalar loads), and because
+// x is the fast grid dimension the chip works through one level at a time -- the live part of the
+// table is one level (T*F*2 bytes: 2 MiB at the reference size), which an XCD's 4 MiB L2 holds.
+#include "hash_grid.hiph"
+
+namespace
+{
+
+// ---------------------------------------------------------------------------- table cast -------
+
+__global__ __launch_bounds__(F2N_BLOCK) void table_to_f16_kernel(
+  const float * __restrict__ in, uint16_t * __restrict__ out, int64_t n)
+{
+  // 8 elements per thread: 2 x 16-B loads, 1 x 16-B store
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 8;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < n; i += stride) {
+    if (i + 8 <= n) {
+      const float4 a = *reinterpret_cast<const float4 *>(in + i);
+      const float4 b = *reinterpret_cast<const float4 *>(in + i + 4);
+      uint4 o;
+      o.x = (uint32_t)__half_as_ushort(__float2half_rn(a.x)) |
+            ((uint32_t)__half_as_ushort(__float2half_rn(a.y)) << 16);
+      o.y = (uint32_t)__half_as_ushort(__float2half_rn(a.z)) |
+            ((uint32_t)__half_as_ushort(__float2half_rn(a.w)) << 16);
+      o.z = (uint32_t)__half_as_ushort(__float2half_rn(b.x)) |
+            ((uint32_t)__half_as_ushort(__float2half_rn(b.y)) << 16);
+      o.w = (uint32_t)__half_as_ushort(__float2half_rn(b.z)) |
+            ((uint32_t)__half_as_ushort(__float2half_rn(b.w)) << 16);
+      *reinterpret_cast<uint4 *>(out + i) = o;
+    } else {
+      for (int64_t j = i; j < n; j++) out[j] = __half_as_ushort(__float2half_rn(in[j]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- forward ----------
+
+template <int F, bool POW2>
+__global__ __launch_bounds__(F2N_BLOCK) void hash_fwd_kernel(
+  const float * __restrict__ pts, const uint16_t * __restrict__ table,
+  const int32_t * __restrict__ primes, const float * __restrict__ bias,
+  const float * __restrict__ mul, float * __restrict__ out, int64_t out_ld_point,
+  int64_t out_ld_chan, uint32_t * __restrict__ idx_out, int64_t n, int L, uint32_t T,
+  int64_t level_stride)
+{
+  const int l = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * F2N_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const LevelParams lp = load_level(primes, bias, mul, l);
+  const float x = pts[3 * p + 0], y = pts[3 * p + 1], z = pts[3 * p + 2];
+  uint32_t row[8];
+  float w[8];
+  corner_rows_and_weights<POW2>(x, y, z, lp, T, row, w);
+  float acc[F];
+  gather_blend<F>(table + level_stride * l, row, w, acc);
+  float * o = out + p * out_ld_point + (int64_t)(l * F) * out_ld_chan;
+#pragma unroll
+  for (int k = 0; k < F; k++) o[k * out_ld_chan] = round_f16(acc[k]);
+  if (idx_out) {
+    uint32_t * io = idx_out + (p * L + l) * 8;
+#pragma unroll
+    for (int d = 0; d < 8; d++) io[d] = row[d];
+  }
+}
+
+// ---------------------------------------------------------------------------- backward ---------
+
+// v1: one thread per (point, level); 8*F f32 atomics into the table gradient.  Contributions are
+// f16(f16(scale*g) * w_d) exactly as the reference forms them; the running sum is f32 and already
+// divided by the (power-of-two) scale, so no epilogue pass over the table is needed.
+template <int F, bool POW2, bool WITH_PTS_GRAD>
+__global__ __launch_bounds__(F2N_BLOCK) void hash_bwd_kernel(
+  const float * __restrict__ pts, const uint16_t * __restrict__ table,
+  const int32_t * __restrict__ primes, const float * __restrict__ bias,
+  const float * __restrict__ mul, const float * __restrict__ grad_out, int64_t g_ld_point,
+  int64_t g_ld_chan, float * __restrict__ table_grad, float * __restrict__ pts_grad, int64_t n,
+  uint32_t T, int64_t level_stride, float grad_scale, float inv_scale)
+{
+  const int l = blockIdx.y;
+  const int64_t p = (int64_t)blockIdx.x * F2N_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const LevelParams lp = load_level(primes, bias, mul, l);
+  const float x = pts[3 * p + 0], y = pts[3 * p + 1], z = pts[3 * p + 2];
+  uint32_t row[8];
+  float w[8];
+  corner_rows_and_weights<POW2>(x, y, z, lp, T, row, w);
+
+  const float * g = grad_out + p * g_ld_point + (int64_t)(l * F) * g_ld_chan;
+  float gk[F];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < F; k++) {
+    gk[k] = round_f16(g[k * g_ld_chan] * grad_scale);
+    any |= (gk[k] != 0.f);
+  }
+  float * gbase = table_grad + level_stride * l;
+  if (any) {  // reference skips all-zero channel pairs (:133); adding zeros changes nothing
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+#pragma unroll
+      for (int k = 0; k < F; k++) {
+        const float c = round_f16(gk[k] * w[d]) * inv_scale;
+        atomicAdd(gbase + (int64_t)row[d] * F + k, c);
+      }
+    }
+  }
+  if (WITH_PTS_GRAD) {
+    // quirk Q5: sign * feature * mul * g per corner and channel, each rounded to f16 (:138-143)
+    using Row = typename RowBits<F>::type;
+    const Row * rows = reinterpret_cast<const Row *>(table + level_stride * l);
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      float f[F];
+      const Row r = rows[row[d]];
+      unpack_row<F>(r, f);
+#pragma unroll
+      for (int k = 0; k < F; k++) {
+        const float nrm = f[k] * lp.mul * gk[k];
+        const float pos = round_f16(nrm), neg = round_f16(-nrm);
+        gx += (d & 4) ? pos : neg;
+        gy += (d & 2) ? pos : neg;
+        gz += (d & 1) ? pos : neg;
+      }
+    }
+    atomicAdd(pts_grad + 3 * p + 0, gx * inv_scale);
+    atomicAdd(pts_grad + 3 * p + 1, gy * inv_scale);
+    atomicAdd(pts_grad + 3 * p + 2, gz * inv_scale);
+  }
+}
+
+// ---------------------------------------------------------------------------- contraction ------
+
+__global__ __launch_bounds__(F2N_BLOCK) void contract_fwd_kernel(
+  const float * __restrict__ pts, float * __restrict__ out, int64_t n)
+{
+  const int64_t p = (int64_t)blockIdx.x * F2N_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
+  contract_point(x, y, z);
+  out[3 * p] = x;
+  out[3 * p + 1] = y;
+  out[3 * p + 2] = z;
+}
+
+// d/dp of x = a(|p|) p with a = 2/n - 1/n^2 outside the unit ball, identity inside.
+__global__ __launch_bounds__(F2N_BLOCK) void contract_bwd_kernel(
+  const float * __restrict__ pts, const float * __restrict__ dx, float * __restrict__ dp, int64_t n)
+{
+  const int64_t p = (int64_t)blockIdx.x * F2N_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const float x = pts[3 * p], y = pts[3 * p + 1], z = pts[3 * p + 2];
+  const float gx = dx[3 * p], gy = dx[3 * p + 1], gz = dx[3 * p + 2];
+  const float n2 = fmaf(z, z, fmaf(y, y, x * x));
+  const float nrm = sqrtf(n2);
+  float ox, oy, oz;
+  if (nrm <= 1.f) {
+    const float poison = (nrm == 0.f) ? __builtin_nanf("") : 0.f;
+    ox = gx + poison;
+    oy = gy + poison;
+    oz = gz + poison;
+  } else {
+    const float inv = 1.f / nrm;
+    const float a = (2.f - inv) * inv;                       // 2/n - 1/n^2
+    const float da_over_n = (2.f * inv - 2.f) * inv * inv * inv;  // a'(n)/n = (-2/n^2 + 2/n^3)/n
+    const float pg = fmaf(z, gz, fmaf(y, gy, x * gx));
+    const float c = da_over_n * pg;
+    ox = fmaf(c, x, a * gx);
+    oy = fmaf(c, y, a * gy);
+    oz = fmaf(c, z, a * gz);
+  }
+  dp[3 * p] = ox;
+  dp[3 * p + 1] = oy;
+  dp[3 * p + 2] = oz;
+}
+
+inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1u)); }
+
+inline bool hash_args_ok(int64_t n, int L, int F, uint32_t T, int64_t level_stride)
+{
+  return n >= 0 && L >= 1 && L <= F2N_MAX_LEVELS && T >= 1 && level_stride >= 0 &&
+         (F == 1 || F == 2 || F == 4 || F == 8) && (level_stride % F) == 0;
+}
+
+}  // namespace
+
+extern "C" int f2n_table_to_f16(
+  const float * table_f32, uint16_t * table_f16, int64_t n, void * stream)
+{
+  if (!table_f32 || !table_f16 || n < 0) return F2N_E_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  if ((reinterpret_cast<uintptr_t>(table_f32) & 15u) || (reinterpret_cast<uintptr_t>(table_f16) & 15u))
+    return F2N_E_INVALID_ARG;
+  const int64_t work = (n + 7) / 8;
+  const unsigned grid = (unsigned)std::min<int64_t>((work + F2N_BLOCK - 1) / F2N_BLOCK, 256 * 16);
+  hipLaunchKernelGGL(
+    table_to_f16_kernel, dim3(grid), dim3(F2N_BLOCK), 0, (hipStream_t)stream, table_f32, table_f16,
+    n);
+  return f2n_launch_status();
+}
+
+#define F2N_DISPATCH_F(F_, ...)      \
+  switch (F_) {                      \
+    case 1: { constexpr int FF = 1; __VA_ARGS__; } break; \
+    case 2: { constexpr int FF = 2; __VA_ARGS__; } break; \
+    case 4: { constexpr int FF = 4; __VA_ARGS__; } break; \
+    case 8: { constexpr int FF = 8; __VA_ARGS__; } break; \
+    default: return F2N_E_UNSUPPORTED; \
+  }
+
+extern "C" int f2n_hash_fwd(
+  const float * pts, const uint16_t * table_f16, const int32_t * primes, const float * bias,
+  const float * mul, float * out, int64_t out_ld_point, int64_t out_ld_chan, uint32_t * idx_out,
+  int64_t n, int L, int F, uint32_t T, int64_t level_stride, void * stream)
+{
+  if (!pts || !table_f16 || !primes || !bias || !mul || !out) return F2N_E_INVALID_ARG;
+  if (F != 1 && F != 2 && F != 4 && F != 8) return F2N_E_UNSUPPORTED;
+  if (!hash_args_ok(n, L, F, T, level_stride)) return F2N_E_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(table_f16) % (2u * F)) return F2N_E_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  const dim3 grid(f2n_div_up(n, F2N_BLOCK), (unsigned)L), block(F2N_BLOCK);
+  hipStream_t s = (hipStream_t)stream;
+  const bool p2 = is_pow2(T);
+  F2N_DISPATCH_F(F, {
+    if (p2)
+      hipLaunchKernelGGL(
+        (hash_fwd_kernel<FF, true>), grid, block, 0, s, pts, table_f16, primes, bias, mul, out,
+        out_ld_point, out_ld_chan, idx_out, n, L, T, level_stride);
+    else
+      hipLaunchKernelGGL(
+        (hash_fwd_kernel<FF, false>), grid, block, 0, s, pts, table_f16, primes, bias, mul, out,
+        out_ld_point, out_ld_chan, idx_out, n, L, T, level_stride);
+  })
+  return f2n_launch_status();
+}
+
+extern "C" int f2n_hash_bwd(
+  const float * pts, const uint16_t * table_f16, const int32_t * primes, const float * bias,
+  const float * mul, const float * grad_out, int64_t g_ld_point, int64_t g_ld_chan,
+  float * table_grad, float * pts_grad, int64_t n, int L, int F, uint32_t T, int64_t level_stride,
+  float grad_scale, void * stream)
+{
+  if (!pts || !table_f16 || !primes || !bias || !mul || !grad_out || !table_grad)
+    return F2N_E_INVALID_ARG;
+  if (F != 1 && F != 2 && F != 4 && F != 8) return F2N_E_UNSUPPORTED;
+  if (!hash_args_ok(n, L, F, T, level_stride)) return F2N_E_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(table_f16) % (2u * F)) return F2N_E_INVALID_ARG;
+  int e = 0;
+  const float m = frexpf(grad_scale, &e);
+  if (!(grad_scale > 0.f) || m != 0.5f) return F2N_E_INVALID_ARG;  // power of two only
+  if (n == 0) return F2N_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (pts_grad) {
+    if (hipMemsetAsync(pts_grad, 0, sizeof(float) * 3 * n, s) != hipSuccess) return F2N_E_LAUNCH;
+  }
+  const dim3 grid(f2n_div_up(n, F2N_BLOCK), (unsigned)L), block(F2N_BLOCK);
+  const bool p2 = is_pow2(T);
+  const float inv = 1.f / grad_scale;
+#define F2N_BWD_LAUNCH(P2, PG)                                                                    \
+  hipLaunchKernelGGL(                                                                             \
+    (hash_bwd_kernel<FF, P2, PG>), grid, block, 0, s, pts, table_f16, primes, bias, mul, grad_out, \
+    g_ld_point, g_ld_chan, table_grad, pts_grad, n, T, level_stride, grad_scale, inv)
+  F2N_DISPATCH_F(F, {
+    if (p2) {
+      if (pts_grad) F2N_BWD_LAUNCH(true, true);
+      else F2N_BWD_LAUNCH(true, false);
+    } else {
+      if (pts_grad) F2N_BWD_LAUNCH(false, true);
+      else F2N_BWD_LAUNCH(false, false);
+    }
+  })
+#undef F2N_BWD_LAUNCH
+  return f2n_launch_status();
+}
+
+extern "C" int f2n_contract_fwd(const float * pts, float * x, int64_t n, void * stream)
+{
+  if (!pts || !x || n < 0) return F2N_E_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  hipLaunchKernelGGL(
+    contract_fwd_kernel, dim3(f2n_div_up(n, F2N_BLOCK)), dim3(F2N_BLOCK), 0, (hipStream_t)stream,
+    pts, x, n);
+  return f2n_launch_status();
+}
+
+extern "C" int f2n_contract_bwd(
+  const float * pts, const float * dx, float * dpts, int64_t n, void * stream)
+{
+  if (!pts || !dx || !dpts || n < 0) return F2N_E_INVALID_ARG;
+  if (n == 0) return F2N_OK;
+  hipLaunchKernelGGL(
+    contract_bwd_kernel, dim3(f2n_div_up(n, F2N_BLOCK)), dim3(F2N_BLOCK), 0, (hipStream_t)stream,
+    pts, dx, dpts, n);
+  return f2n_launch_status();
+}

@@ -1,0 +1,329 @@
+// sampler.hip -- ray sampling, the fused early-termination march and sample compaction
+// (SURVEY.md rows A4, A5).
+//
+// Replaces PtsSampler::get_samples (about 20 ATen launches, reference src/points_sampler.cpp:20-64)
+// and the early-stop block of Renderer::render (src/renderer.cpp:58-90), which in the reference
+// evaluates the whole field on all n_rays*S samples only to build a keep-mask and then runs
+// where() + four index() gathers.
+//
+// Mapping: one 64-lane wavefront per ray, lanes = 64 consecutive samples (a "stride").  Cumulative
+// step noise and the exclusive optical-depth scan are DPP wave scans with a scalar carry between
+// strides; the keep-mask is a wave ballot; a ray whose transmittance has dropped to <= t_thresh
+// stops issuing strides, so a terminated ray costs ceil(kept/64) strides, not S/64.
+#include "hash_grid.hiph"
+
+namespace
+{
+
+struct RayFrame
+{
+  float ox, oy, oz;
+  float dx, dy, dz;  // unit direction
+};
+
+// rays_d / linalg_norm(rays_d, 2, -1, true)  (points_sampler.cpp:24)
+__device__ __forceinline__ RayFrame load_ray(
+  const float * __restrict__ rays_o, const float * __restrict__ rays_d, int r)
+{
+  RayFrame rf;
+  rf.ox = rays_o[3 * r];
+  rf.oy = rays_o[3 * r + 1];
+  rf.oz = rays_o[3 * r + 2];
+  const float x = rays_d[3 * r], y = rays_d[3 * r + 1], z = rays_d[3 * r + 2];
+  const float nrm = sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+  rf.dx = x / nrm;
+  rf.dy = y / nrm;
+  rf.dz = z / nrm;
+  return rf;
+}
+
+struct StrideCarry
+{
+  float noise;       // cumulative noise up to the previous stride
+  float lx, ly, lz;  // last sample point of the previous stride
+};
+
+struct StrideSample
+{
+  float t, px, py, pz, dt;
+  bool valid;
+};
+
+// Samples k0 .. k0+63 of one ray (points_sampler.cpp:31-48):
+//   t_k = cumsum(noise)_k * step ; p_k = o + d*t_k (mul, then add -- two ATen ops, not fused) ;
+//   dt_0 = 0, dt_k = |p_k - p_{k-1}|   (differences of points, quirk Q7)
+// The same function feeds f2n_sample_rays, f2n_density_march and f2n_sample_compact so that all
+// three see bit-identical samples.
+__device__ __forceinline__ StrideSample make_stride(
+  const RayFrame & rf, const float * __restrict__ noise_row, int k0, int S, float step,
+  StrideCarry & carry, int lane)
+{
+  StrideSample sm;
+  const int k = k0 + lane;
+  sm.valid = k < S;
+  float cum;
+  if (noise_row) {
+    const float nz = sm.valid ? noise_row[k] : 0.f;
+    cum = carry.noise + wave_incl_scan(nz);
+  } else {
+    cum = (float)(min(k, S - 1) + 1);  // cumsum of ones is exact
+  }
+  sm.t = cum * step;
+  const float mx = rf.dx * sm.t, my = rf.dy * sm.t, mz = rf.dz * sm.t;
+  sm.px = rf.ox + mx;
+  sm.py = rf.oy + my;
+  sm.pz = rf.oz + mz;
+  const float qx = wave_shift_up1(sm.px, carry.lx);
+  const float qy = wave_shift_up1(sm.py, carry.ly);
+  const float qz = wave_shift_up1(sm.pz, carry.lz);
+  const float ex = sm.px - qx, ey = sm.py - qy, ez = sm.pz - qz;
+  sm.dt = (k == 0) ? 0.f : sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+  carry.noise = wave_bcast_last(cum);
+  carry.lx = wave_bcast_last(sm.px);
+  carry.ly = wave_bcast_last(sm.py);
+  carry.lz = wave_bcast_last(sm.pz);
+  return sm;
+}
+
+__device__ __forceinline__ int ray_of_wave()
+{
+  return (int)blockIdx.x * F2N_WAVES_PER_BLOCK + (int)(threadIdx.x >> 6);
+}
+
+// ---- f2n_sample_rays ----------------------------------------------------------------------------
+
+__global__ __launch_bounds__(F2N_BLOCK) void sample_rays_kernel(
+  const float * __restrict__ rays_o, const float * __restrict__ rays_d,
+  const float * __restrict__ noise, float * __restrict__ pts, float * __restrict__ dirs,
+  float * __restrict__ dt, float * __restrict__ t, int32_t * __restrict__ bounds, int n_rays, int S,
+  float step)
+{
+  const int r = ray_of_wave();
+  if (r >= n_rays) return;
+  const int lane = lane_id();
+  const RayFrame rf = load_ray(rays_o, rays_d, r);
+  const float * nrow = noise ? noise + (int64_t)r * S : nullptr;
+  StrideCarry carry = {0.f, 0.f, 0.f, 0.f};
+  const int64_t base = (int64_t)r * S;
+  for (int k0 = 0; k0 < S; k0 += F2N_WAVE) {
+    const StrideSample sm = make_stride(rf, nrow, k0, S, step, carry, lane);
+    if (sm.valid) {
+      const int64_t i = base + k0 + lane;
+      pts[3 * i] = sm.px;
+      pts[3 * i + 1] = sm.py;
+      pts[3 * i + 2] = sm.pz;
+      dirs[3 * i] = rf.dx;
+      dirs[3 * i + 1] = rf.dy;
+      dirs[3 * i + 2] = rf.dz;
+      dt[i] = sm.dt;
+      t[i] = sm.t;
+    }
+  }
+  if (lane == 0) {
+    bounds[2 * r] = (int32_t)base;
+    bounds[2 * r + 1] = (int32_t)(base + S);
+  }
+}
+
+// ---- f2n_sample_compact -------------------------------------------------------------------------
+
+__global__ __launch_bounds__(F2N_BLOCK) void sample_compact_kernel(
+  const float * __restrict__ rays_o, const float * __restrict__ rays_d,
+  const float * __restrict__ noise, const int32_t * __restrict__ bounds, float * __restrict__ pts,
+  float * __restrict__ dirs, float * __restrict__ dt, float * __restrict__ t, int n_rays, int S,
+  float step)
+{
+  const int r = ray_of_wave();
+  if (r >= n_rays) return;
+  const int lane = lane_id();
+  const int start = bounds[2 * r];
+  const int cnt = bounds[2 * r + 1] - start;
+  if (cnt <= 0) return;
+  const RayFrame rf = load_ray(rays_o, rays_d, r);
+  const float * nrow = noise ? noise + (int64_t)r * S : nullptr;
+  StrideCarry carry = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < cnt; k0 += F2N_WAVE) {
+    const StrideSample sm = make_stride(rf, nrow, k0, S, step, carry, lane);
+    if (k0 + lane < cnt) {
+      const int64_t i = (int64_t)start + k0 + lane;
+      pts[3 * i] = sm.px;
+      pts[3 * i + 1] = sm.py;
+      pts[3 * i + 2] = sm.pz;
+      dirs[3 * i] = rf.dx;
+      dirs[3 * i + 1] = rf.dy;
+      dirs[3 * i + 2] = rf.dz;
+      dt[i] = sm.dt;
+      t[i] = sm.t;
+    }
+  }
+}
+
+// ---- f2n_density_march --------------------------------------------------------------------------
+
+template <int F, bool POW2>
+__global__ __launch_bounds__(F2N_BLOCK) void density_march_kernel(
+  const float * __restrict__ rays_o, const float * __restrict__ rays_d,
+  const float * __restrict__ noise, const uint16_t * __restrict__ table,
+  const int32_t * __restrict__ primes, const float * __restrict__ bias,
+  const float * __restrict__ mul, const float * __restrict__ w0, const float * __restrict__ b0,
+  int32_t * __restrict__ kept, int n_rays, int S, float step, int L, uint32_t T,
+  int64_t level_stride, float t_thresh, float density_shift)
+{
+  const int r = ray_of_wave();
+  if (r >= n_rays) return;
+  const int lane = lane_id();
+  const RayFrame rf = load_ray(rays_o, rays_d, r);
+  const float * nrow = noise ? noise + (int64_t)r * S : nullptr;
+  const float bias0 = b0[0];
+  StrideCarry carry = {0.f, 0.f, 0.f, 0.f};
+  float depth_carry = 0.f;  // optical depth accumulated by earlier strides
+  int n_kept = 0;
+  for (int k0 = 0; k0 < S; k0 += F2N_WAVE) {
+    const StrideSample sm = make_stride(rf, nrow, k0, S, step, carry, lane);
+    float x = sm.px, y = sm.py, z = sm.pz;
+    contract_point(x, y, z);
+    // density logit = row 0 of Linear(L*F -> 16) applied to the f16-rounded encoding
+    float logit = bias0;
+    for (int l = 0; l < L; l++) {
+      const LevelParams lp = load_level(primes, bias, mul, l);
+      uint32_t row[8];
+      float w[8], acc[F];
+      corner_rows_and_weights<POW2>(x, y, z, lp, T, row, w);
+      gather_blend<F>(table + level_stride * l, row, w, acc);
+#pragma unroll
+      for (int k = 0; k < F; k++) logit = fmaf(round_f16(acc[k]), w0[l * F + k], logit);
+    }
+    const float sigma = expf(logit - density_shift);   // TruncExp forward
+    const float sec = sm.valid ? sigma * sm.dt : 0.f;  // sigma * dt
+    const float incl = wave_incl_scan(sec);
+    const float depth = depth_carry + wave_shift_up1(incl, 0.f);  // exclusive scan
+    const float trans = expf(-depth);
+    const bool keep = sm.valid && (trans > t_thresh);
+    const unsigned long long m = __ballot(keep);
+    n_kept += __popcll(m);
+    const int n_valid = min(F2N_WAVE, S - k0);
+    if (__popcll(m) < n_valid) break;  // the mask is a prefix: nothing later survives
+    depth_carry += wave_bcast_last(incl);
+  }
+  if (lane == 0) kept[r] = n_kept;
+}
+
+// ---- f2n_bounds_from_counts ---------------------------------------------------------------------
+
+constexpr int kScanBlock = 1024;
+constexpr int kScanItems = 4;
+
+__global__ __launch_bounds__(kScanBlock) void bounds_from_counts_kernel(
+  const int32_t * __restrict__ kept, int32_t * __restrict__ bounds, int32_t * __restrict__ total,
+  int n_rays)
+{
+  __shared__ int wave_tot[kScanBlock / F2N_WAVE];
+  __shared__ int tile_tot;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int carry = 0;
+  for (int base = 0; base < n_rays; base += kScanBlock * kScanItems) {
+    const int i0 = base + tid * kScanItems;
+    int v[kScanItems];
+    int local = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+      v[j] = (i0 + j < n_rays) ? kept[i0 + j] : 0;
+      local += v[j];
+    }
+    const int incl = wave_incl_scan_i32(local);
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+      const int wt = (lane < kScanBlock / F2N_WAVE) ? wave_tot[lane] : 0;
+      const int wi = wave_incl_scan_i32(wt);
+      if (lane < kScanBlock / F2N_WAVE) wave_tot[lane] = wi - wt;  // exclusive wave offsets
+      if (lane == 63) tile_tot = wi;
+    }
+    __syncthreads();
+    int run = carry + wave_tot[wv] + (incl - local);
+#pragma unroll
+    for (int j = 0; j < kScanItems; j++) {
+      if (i0 + j < n_rays) {
+        bounds[2 * (i0 + j)] = run;
+        bounds[2 * (i0 + j) + 1] = run + v[j];
+      }
+      run += v[j];
+    }
+    carry += tile_tot;
+    __syncthreads();
+  }
+  if (tid == 0 && total) total[0] = carry;
+}
+
+inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1u)); }
+
+}  // namespace
+
+extern "C" int f2n_sample_rays(
+  const float * rays_o, const float * rays_d, const float * noise, float * pts, float * dirs,
+  float * dt, float * t, int32_t * bounds, int n_rays, int S, float step, void * stream)
+{
+  if (n_rays < 0 || S < 1) return F2N_E_INVALID_ARG;
+  if ((int64_t)n_rays * S > INT32_MAX) return F2N_E_INVALID_ARG;  // bounds are int32
+  if (n_rays == 0) return F2N_OK;
+  if (!rays_o || !rays_d || !pts || !dirs || !dt || !t || !bounds) return F2N_E_INVALID_ARG;
+  hipLaunchKernelGGL(
+    sample_rays_kernel, dim3(f2n_div_up(n_rays, F2N_WAVES_PER_BLOCK)), dim3(F2N_BLOCK), 0,
+    (hipStream_t)stream, rays_o, rays_d, noise, pts, dirs, dt, t, bounds, n_rays, S, step);
+  return f2n_launch_status();
+}
+
+extern "C" int f2n_sample_compact(
+  const float * rays_o, const float * rays_d, const float * noise, const int32_t * bounds,
+  float * pts, float * dirs, float * dt, float * t, int n_rays, int S, float step, void * stream)
+{
+  if (n_rays < 0 || S < 1) return F2N_E_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  if (!rays_o || !rays_d || !bounds) return F2N_E_INVALID_ARG;
+  hipLaunchKernelGGL(
+    sample_compact_kernel, dim3(f2n_div_up(n_rays, F2N_WAVES_PER_BLOCK)), dim3(F2N_BLOCK), 0,
+    (hipStream_t)stream, rays_o, rays_d, noise, bounds, pts, dirs, dt, t, n_rays, S, step);
+  return f2n_launch_status();
+}
+
+extern "C" int f2n_density_march(
+  const float * rays_o, const float * rays_d, const float * noise, const uint16_t * table_f16,
+  const int32_t * primes, const float * bias, const float * mul, const float * w0, const float * b0,
+  int32_t * kept, int n_rays, int S, float step, int L, int F, uint32_t T, int64_t level_stride,
+  float t_thresh, float density_shift, void * stream)
+{
+  if (n_rays < 0 || S < 1 || L < 1 || L > F2N_MAX_LEVELS || T < 1 || level_stride < 0)
+    return F2N_E_INVALID_ARG;
+  if (F != 1 && F != 2 && F != 4 && F != 8) return F2N_E_UNSUPPORTED;
+  if (level_stride % F) return F2N_E_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  if (!rays_o || !rays_d || !table_f16 || !primes || !bias || !mul || !w0 || !b0 || !kept)
+    return F2N_E_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(table_f16) % (2u * F)) return F2N_E_INVALID_ARG;
+  const dim3 grid(f2n_div_up(n_rays, F2N_WAVES_PER_BLOCK)), block(F2N_BLOCK);
+  hipStream_t s = (hipStream_t)stream;
+  const bool p2 = is_pow2(T);
+#define F2N_MARCH(FF, P2)                                                                         \
+  hipLaunchKernelGGL(                                                                             \
+    (density_march_kernel<FF, P2>), grid, block, 0, s, rays_o, rays_d, noise, table_f16, primes,  \
+    bias, mul, w0, b0, kept, n_rays, S, step, L, T, level_stride, t_thresh, density_shift)
+  switch (F) {
+    case 1: if (p2) F2N_MARCH(1, true); else F2N_MARCH(1, false); break;
+    case 2: if (p2) F2N_MARCH(2, true); else F2N_MARCH(2, false); break;
+    case 4: if (p2) F2N_MARCH(4, true); else F2N_MARCH(4, false); break;
+    default: if (p2) F2N_MARCH(8, true); else F2N_MARCH(8, false); break;
+  }
+#undef F2N_MARCH
+  return f2n_launch_status();
+}
+
+extern "C" int f2n_bounds_from_counts(
+  const int32_t * kept, int32_t * bounds, int32_t * total, int n_rays, void * stream)
+{
+  if (n_rays < 0 || n_rays > (1 << 24)) return F2N_E_INVALID_ARG;
+  if (n_rays > 0 && (!kept || !bounds)) return F2N_E_INVALID_ARG;
+  hipLaunchKernelGGL(
+    bounds_from_counts_kernel, dim3(1), dim3(kScanBlock), 0, (hipStream_t)stream, kept, bounds,
+    total, n_rays);
+  return f2n_launch_status();
+}

@@ -1,0 +1,184 @@
+/*
+ * f2nerf_hip.h -- C ABI of libf2nerf_hip.so: the MI355X (gfx950) kernels behind the F2-NeRF
+ * rendering hot path (hash-grid encode, ray sampling / early termination, SH encode, ragged per-ray
+ * compositing; forward and backward).
+ *
+ * This is the drop-in boundary.  Every entry point replaces one CUDA kernel launch site (or one
+ * run of ATen launches) of SakodaShintaro/f2-nerf; the reference interface each one stands in for
+ * is cited as file:line (relative to the reference checkout).  INTEGRATION.md shows the LibTorch
+ * wrappers that bind them.
+ *
+ * Conventions (inherited from the reference's launch sites):
+ *   - all pointers are DEVICE pointers to contiguous, caller-owned, caller-allocated buffers;
+ *   - no entry point allocates, frees, synchronises or keeps state between calls (calls arrive
+ *     from the forward thread and from the autograd engine's device thread);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - return value: F2N_OK (0) or a negative F2N_E_* code; nothing throws;
+ *   - counts are elements, never bytes; `idx`/`bounds` are [n_rays, 2] int32 {start, end}.
+ */
+#ifndef F2NERF_HIP_H_
+#define F2NERF_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define F2N_ABI_VERSION 1
+
+#define F2N_OK 0
+#define F2N_E_INVALID_ARG (-1) /* null pointer, negative count, unsupported L/F/degree ...     */
+#define F2N_E_LAUNCH (-2)      /* hipGetLastError() != hipSuccess right after the launch        */
+#define F2N_E_UNSUPPORTED (-3) /* valid request the build does not cover (e.g. F not in 1,2,4,8) */
+
+#define F2N_MAX_LEVELS 32
+
+int f2n_abi_version(void);
+const char * f2n_status_string(int status);
+
+/* ------------------------------------------------------------------ hash grid (rows A1, A2) --- */
+
+/* feat_pool.to(torch::kFloat16) -- src/hash_3d_anchored.cu:169,198.  RNE cast of n elements. */
+int f2n_table_to_f16(const float * table_f32, uint16_t * table_f16, int64_t n, void * stream);
+
+/* Hash3DAnchoredForwardKernel<__half><<<(ceil(n/512), L), 512>>> + out.to(kFloat32)
+ * -- src/hash_3d_anchored.cu:60-93,164-178.
+ *   pts        [n,3] f32, already contracted
+ *   table_f16  f16 pool; level l starts at element level_stride*l (reference: level_stride = T,
+ *              quirk Q2), rows of F channels, row index = hash % T
+ *   primes     [L,3] i32; bias [L,3] f32; mul [L] f32 (host table, see f2n_level_mul in the host lib)
+ *   out        f32 holding the f16-rounded feature; element (p, c) at out[p*out_ld_point + c*out_ld_chan],
+ *              c = l*F + k.  Reference layout: out_ld_point = L*F, out_ld_chan = 1.
+ *   idx_out    optional [n, L, 8] u32 hash rows (parity tests); NULL in production. */
+int f2n_hash_fwd(
+  const float * pts, const uint16_t * table_f16, const int32_t * primes, const float * bias,
+  const float * mul, float * out, int64_t out_ld_point, int64_t out_ld_chan, uint32_t * idx_out,
+  int64_t n, int L, int F, uint32_t T, int64_t level_stride, void * stream);
+
+/* Hash3DAnchoredBackwardKernel<__half> + the /grad_scale epilogue
+ * -- src/hash_3d_anchored.cu:95-145,190-215.
+ *   grad_out    element (p, c) at grad_out[p*g_ld_point + c*g_ld_chan], f32
+ *   table_grad  f32, same element indexing as table_f16, ACCUMULATED INTO (caller zeroes it):
+ *               += f16(f16(grad_scale*g) * w_d) / grad_scale per corner.  The reference accumulates
+ *               with order-dependent f16 atomics; here the sum is kept in f32 (documented in
+ *               DESIGN.md).  grad_scale must be a power of two (reference: 128).
+ *   pts_grad    [n,3] f32 or NULL (NULL = points need no gradient: the training case).  Overwritten. */
+int f2n_hash_bwd(
+  const float * pts, const uint16_t * table_f16, const int32_t * primes, const float * bias,
+  const float * mul, const float * grad_out, int64_t g_ld_point, int64_t g_ld_chan,
+  float * table_grad, float * pts_grad, int64_t n, int L, int F, uint32_t T, int64_t level_stride,
+  float grad_scale, void * stream);
+
+/* Scene contraction of Hash3DAnchored::query -- src/hash_3d_anchored.cpp:79-82 (8 ATen launches):
+ *   x = p if |p| <= 1 else (2 - 1/|p|) * p/|p|, evaluated as the reference's mask expression
+ *   (|p| == 0 gives NaN, quirk Q6).  The backward is the Jacobian-vector product autograd builds. */
+int f2n_contract_fwd(const float * pts, float * x, int64_t n, void * stream);
+int f2n_contract_bwd(const float * pts, const float * dx, float * dpts, int64_t n, void * stream);
+
+/* ------------------------------------------------------------------ SH encode (row A6) -------- */
+
+/* SHKernel<<<ceil(n/512), 512>>> -- src/sh_shader.cu:11-115.  dirs [n,3] -> out [n, degree^2]. */
+int f2n_sh_encode(const float * dirs, float * out, int64_t n, int degree, void * stream);
+
+/* ------------------------------------------------------------------ ragged per-ray ops (A7) --- */
+
+/* FlexSumForwardKernel / BackwardKernel -- src/CustomOps/FlexOps.cu:6-27,98-153 */
+int f2n_seg_sum_fwd(const float * val, const int32_t * idx, float * sum, int n_rays, void * stream);
+int f2n_seg_sum_bwd(const float * dsum, const int32_t * idx, float * dval, int n_rays, void * stream);
+/* FlexSumVecForwardKernel / BackwardKernel -- src/CustomOps/FlexOps.cu:29-54 */
+int f2n_seg_sum_vec_fwd(
+  const float * val, const int32_t * idx, float * sum, int n_rays, int vec, void * stream);
+int f2n_seg_sum_vec_bwd(
+  const float * dsum, const int32_t * idx, float * dval, int n_rays, int vec, void * stream);
+/* FlexAccumulateSumForwardKernel / BackwardKernel -- src/CustomOps/FlexOps.cu:56-94,155-199 */
+int f2n_seg_scan_fwd(
+  const float * val, const int32_t * idx, float * sum, int n_rays, int include_this, void * stream);
+int f2n_seg_scan_bwd(
+  const float * dsum, const int32_t * idx, float * dval, int n_rays, int include_this,
+  void * stream);
+
+/* WeightVarLossForwardKernel / BackwardKernel -- src/CustomOps/CustomOps.cu:13-67 (row A10) */
+int f2n_weight_var_fwd(
+  const float * weights, const int32_t * idx, float * out_vars, int n_rays, void * stream);
+int f2n_weight_var_bwd(
+  const float * weights, const int32_t * idx, const float * dvars, float * dw, int n_rays,
+  void * stream);
+
+/* ------------------------------------------------------------------ scatter (row A9) ---------- */
+
+/* ScatterIdxKernal -- src/CustomOps/Scatter.cu:111-132 */
+int f2n_scatter_idx(
+  const int32_t * idx, const int32_t * emb_idx, int32_t * all_emb_idx, int n_rays, void * stream);
+/* ScatterAddFuncForward (+ the clone at :63) -- src/CustomOps/Scatter.cu:11-19,45-70.
+ * sum[p,c] = to_add[p,c] + emb[scatter_idx[p], c]; sum may alias to_add. */
+int f2n_scatter_add_fwd(
+  const float * emb, const int32_t * scatter_idx, const float * to_add, float * sum, int64_t n_all,
+  int C, void * stream);
+/* ScatterAddFuncBackwardBlock + torch::sum(dim 1) -- src/CustomOps/Scatter.cu:21-41,72-101.
+ * demb [n_emb, C] is overwritten (zeroed, then accumulated) on `stream`. */
+int f2n_scatter_add_bwd(
+  const int32_t * scatter_idx, const float * dsum, float * demb, int64_t n_all, int n_emb, int C,
+  void * stream);
+
+/* ------------------------------------------------------------------ sampler (rows A4, A5) ----- */
+
+/* PtsSampler::get_samples (about 20 ATen launches) -- src/points_sampler.cpp:20-64.
+ *   noise   [n_rays, S] f32 step multipliers (TRAIN: U[0.5,1.5)), or NULL for all-ones (VALIDATE)
+ *   outputs pts [n_rays*S, 3], dirs [n_rays*S, 3], dt [n_rays*S], t [n_rays*S], bounds [n_rays,2]
+ *   S = MAX_SAMPLE_PER_RAY (1024), step = SAMPLE_L (1/256) in the reference (points_sampler.hpp:15,39) */
+int f2n_sample_rays(
+  const float * rays_o, const float * rays_d, const float * noise, float * pts, float * dirs,
+  float * dt, float * t, int32_t * bounds, int n_rays, int S, float step, void * stream);
+
+/* Early-stop pass of Renderer::render fused into one march -- src/renderer.cpp:58-90 together with
+ * points_sampler.cpp:20-64, hash_3d_anchored.cpp:79-86 (contraction, hash encode, row 0 of the
+ * Linear) and CustomOps.cpp:10-14 (TruncExp fwd).  One wavefront walks one ray in 64-sample
+ * strides and stops at the first stride whose transmittance exp(-sum sigma*dt) falls to
+ * <= t_thresh; kept[r] = number of leading samples with T > t_thresh (the mask of :68 is a prefix).
+ *   w0 [L*F] = mlp.weight[0, :], b0 = mlp.bias[0]; density = exp(w0.enc + b0 - density_shift) */
+int f2n_density_march(
+  const float * rays_o, const float * rays_d, const float * noise, const uint16_t * table_f16,
+  const int32_t * primes, const float * bias, const float * mul, const float * w0, const float * b0,
+  int32_t * kept, int n_rays, int S, float step, int L, int F, uint32_t T, int64_t level_stride,
+  float t_thresh, float density_shift, void * stream);
+
+/* cumsum of the per-ray counts -> bounds (renderer.cpp:76-83).  total[0] = sum(kept).
+ * Single-workgroup scan; n_rays <= 2^24. */
+int f2n_bounds_from_counts(
+  const int32_t * kept, int32_t * bounds, int32_t * total, int n_rays, void * stream);
+
+/* where(mask) + the four index() gathers (renderer.cpp:69-74) without materialising the dense
+ * sample arrays: re-derives the first (end-start) samples of each ray straight into the compacted
+ * outputs pts/dirs [n_kept,3], dt/t [n_kept]. */
+int f2n_sample_compact(
+  const float * rays_o, const float * rays_d, const float * noise, const int32_t * bounds,
+  float * pts, float * dirs, float * dt, float * t, int n_rays, int S, float step, void * stream);
+
+/* ------------------------------------------------------------------ compositing (rows A7, A8) - */
+
+/* renderer.cpp:93,107-118 as one pass per ray:
+ *   sigma = exp(logit - density_shift); s = sigma*dt; alpha = 1-exp(-s); T = exp(-excl_scan(s));
+ *   w = T*alpha; T_last = exp(-sum s); C = sum w*rgb + T_last*bg; D = sum w*(t+t_shift)/(1-T_last+1e-4)
+ *   logit element i at logit[i*logit_ld] (column 0 of the [n,16] field output: logit_ld = 16)
+ *   outputs colors [n_rays,3], depths [n_rays], weights [n], last_trans [n_rays] (saved for bwd) */
+int f2n_composite_fwd(
+  const float * logit, int64_t logit_ld, const float * rgb, const float * dt, const float * t,
+  const int32_t * bounds, const float * bg, float * colors, float * depths, float * weights,
+  float * last_trans, int n_rays, float density_shift, float t_shift, void * stream);
+
+/* Backward of the above = FlexSum/FlexSumVec/FlexAccumulateSum backward kernels plus the ATen
+ * element-wise backward and TruncExp::backward (CustomOps.cpp:16-20: exp(clamp(x,-100,5))).
+ *   in : d_colors [n_rays,3], d_depths [n_rays], d_weights [n] (NULL = zeros)
+ *   out: d_logit [n] (dense), d_rgb [n,3] */
+int f2n_composite_bwd(
+  const float * logit, int64_t logit_ld, const float * rgb, const float * dt, const float * t,
+  const int32_t * bounds, const float * bg, const float * weights, const float * last_trans,
+  const float * d_colors, const float * d_depths, const float * d_weights, float * d_logit,
+  float * d_rgb, int n_rays, float density_shift, float t_shift, void * stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* F2NERF_HIP_H_ */

@@ -1,0 +1,261 @@
+"""Parity of every C-ABI kernel (libf2nerf_hip.so, called through ctypes) against the CPU oracle on
+identical seeded inputs.  Integer / index results must be bit-exact; float tolerances are written
+at each assert (north star: 1e-4 relative, hash rows bit-exact)."""
+import pytest
+import torch
+
+from oracle import kernels as K
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _to(dev, *ts):
+    return [t.to(dev) if t is not None else None for t in ts]
+
+
+# --------------------------------------------------------------------------------- hash grid ----
+
+
+@pytest.mark.parametrize("L,F,log2_T,stride_mode", [
+    (16, 2, 19, "ref"),      # the reference's compile-time configuration (overlapping levels, Q2)
+    (4, 2, 19, "ref"),       # BASELINE config C1
+    (16, 8, 14, "disjoint"), # config C5's shape (F=8, non-overlapping stride) at a small T
+    (3, 4, 10, "disjoint"),
+    (5, 1, 12, "ref"),
+])
+def test_hash_fwd_parity(capi, dev, L, F, log2_T, stride_mode):
+    T = 1 << log2_T
+    fld = util.make_field(L, F, log2_T, None if stride_mode == "ref" else T * F, seed=L * 31 + F)
+    n = 20000
+    pts = util.ball_points(n, seed=5)
+    pts[:4] = torch.tensor([[0., 0., 0.], [-2., -2., -2.], [1.9999, 0., 0.], [-1.5, 1.2, -0.3]])
+    ref, ref_idx = K.hash_fwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], L, F, T,
+                              fld["stride"], want_idx=True)
+    d_pts, d_tab, d_pr, d_bias, d_mul = _to(dev, pts, fld["table16"], fld["primes"], fld["bias"],
+                                            fld["mul"])
+    out = torch.empty(n, L * F, device=dev)
+    idx = torch.empty(n, L, 8, dtype=torch.int32, device=dev)
+    capi.call("hash_fwd", d_pts, d_tab, d_pr, d_bias, d_mul, out, L * F, 1, idx, n, L, F, T,
+              fld["stride"])
+    # hash rows: integer work, bit-exact
+    assert torch.equal(idx.cpu(), ref_idx)
+    # values: same FMA order + same f16 rounding -> expected bit-exact; allow 1 f16 ulp on <=1e-4
+    got = out.cpu()
+    diff = (got - ref).abs()
+    exact = (diff == 0).float().mean().item()
+    assert exact >= 1.0 - 1e-4, exact
+    assert (diff <= util.f16_ulp(ref)).all()
+    # channel-major output layout gives the same numbers
+    out_t = torch.empty(L * F, n, device=dev)
+    capi.call("hash_fwd", d_pts, d_tab, d_pr, d_bias, d_mul, out_t, 1, n, None, n, L, F, T,
+              fld["stride"])
+    assert torch.equal(out_t.t().contiguous().cpu(), got)
+
+
+def test_hash_fwd_non_pow2_T_and_empty(capi, dev):
+    L, F, T = 4, 2, 1000
+    fld = util.make_field(L, F, 10, T * F, seed=3)
+    n = 5000
+    pts = util.ball_points(n, seed=9)
+    ref, ref_idx = K.hash_fwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], L, F, T,
+                              T * F, want_idx=True)
+    d = _to(dev, pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"])
+    out = torch.empty(n, L * F, device=dev)
+    idx = torch.empty(n, L, 8, dtype=torch.int32, device=dev)
+    capi.call("hash_fwd", *d, out, L * F, 1, idx, n, L, F, T, T * F)
+    assert torch.equal(idx.cpu(), ref_idx)
+    assert torch.equal(out.cpu(), ref)
+    capi.call("hash_fwd", *d, out, L * F, 1, None, 0, L, F, T, T * F)  # n == 0 is a no-op
+    with pytest.raises(capi.F2NError):
+        capi.call("hash_fwd", *d, out, L * F, 1, None, n, L, 3, T, T * F)  # F=3 unsupported
+
+
+@pytest.mark.parametrize("L,F,log2_T,stride_mode,pts_grad", [
+    (16, 2, 19, "ref", False),
+    (16, 2, 12, "ref", True),
+    (4, 8, 10, "disjoint", True),
+    (6, 4, 11, "disjoint", False),
+])
+def test_hash_bwd_parity(capi, dev, L, F, log2_T, stride_mode, pts_grad):
+    T = 1 << log2_T
+    fld = util.make_field(L, F, log2_T, None if stride_mode == "ref" else T * F, seed=11 + F)
+    n = 8000
+    pts = util.ball_points(n, seed=6)
+    g = torch.Generator().manual_seed(4)
+    grad = torch.randn(n, L * F, generator=g) * 1e-3
+    grad[torch.rand(n, L * F, generator=g) < 0.2] = 0.0
+    numel = fld["table"].numel()
+    ref_tg, ref_pg = K.hash_bwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad,
+                                numel, L, F, T, fld["stride"], 128.0, need_pts_grad=pts_grad)
+    d = _to(dev, pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad)
+    tg = torch.zeros(numel, device=dev)
+    pg = torch.full((n, 3), 7.0, device=dev) if pts_grad else None
+    capi.call("hash_bwd", *d, L * F, 1, tg, pg, n, L, F, T, fld["stride"], 128.0)
+    # each contribution is f16-rounded identically; only the f32 summation order differs
+    scale = ref_tg.abs().max().item()
+    assert (tg.cpu() - ref_tg).abs().max().item() <= 1e-5 * scale
+    assert torch.equal(tg.cpu() != 0, ref_tg != 0) or \
+        ((tg.cpu() != 0) ^ (ref_tg != 0)).float().mean().item() < 1e-6
+    if pts_grad:
+        s = ref_pg.abs().max().item()
+        assert (pg.cpu() - ref_pg).abs().max().item() <= 1e-5 * s + 1e-12
+    # accumulate semantics: a second call doubles the table gradient
+    capi.call("hash_bwd", *d, L * F, 1, tg, None, n, L, F, T, fld["stride"], 128.0)
+    assert (tg.cpu() - 2 * ref_tg).abs().max().item() <= 2e-5 * scale
+
+
+def test_table_cast(capi, dev):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1 << 16, generator=g) * 0.1
+    x[:6] = torch.tensor([65504., 65520., 1e-8, 6e-8, -0.0, 3.0e-5])
+    x = torch.cat([x, torch.randn(13, generator=g)])  # tail not a multiple of 8
+    out = torch.empty(x.numel(), dtype=torch.int16, device=dev)
+    capi.call("table_to_f16", x.to(dev), out, x.numel())
+    assert torch.equal(out.cpu(), K.cast_f16(x))
+
+
+def test_contract(capi, dev):
+    g = torch.Generator().manual_seed(2)
+    p = torch.randn(10000, 3, generator=g) * 2.0
+    p[0] = 0.0                      # quirk Q6: NaN
+    p[1] = torch.tensor([1.0, 0.0, 0.0])  # |p| == 1 stays
+    pr = p.clone().requires_grad_(True)
+    norm = pr.norm(2, dim=1, keepdim=True)
+    mask = norm <= 1.0
+    x = pr * mask + ~mask * (1 + 1.0 - 1.0 / norm) * pr / norm
+    out = torch.empty(p.shape, device=dev)
+    capi.call("contract_fwd", p.to(dev), out, p.shape[0])
+    got = out.cpu()
+    assert torch.isnan(got[0]).all() and torch.isnan(x[0]).all()
+    torch.testing.assert_close(got[1:], x[1:].detach(), rtol=2e-6, atol=1e-7)
+    gx = torch.randn(p.shape, generator=g)
+    x[1:].backward(gx[1:])
+    dp = torch.empty(p.shape, device=dev)
+    capi.call("contract_bwd", p.to(dev), gx.to(dev), dp, p.shape[0])
+    torch.testing.assert_close(dp.cpu()[1:], pr.grad[1:], rtol=1e-4, atol=1e-6)
+
+
+# --------------------------------------------------------------------------------- SH ----------
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 4])
+def test_sh_encode(capi, dev, degree):
+    g = torch.Generator().manual_seed(7)
+    d = torch.randn(30001, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    ref = K.sh_encode(d, degree)
+    out = torch.empty(d.shape[0], degree * degree, device=dev)
+    capi.call("sh_encode", d.to(dev), out, d.shape[0], degree)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-7)
+
+
+# --------------------------------------------------------------------------------- segments -----
+
+
+@pytest.mark.parametrize("n_rays,max_len", [(1, 5), (37, 70), (512, 1024), (3000, 200)])
+def test_segment_ops(capi, dev, n_rays, max_len):
+    idx, n = util.ragged_bounds(n_rays, max_len, seed=n_rays)
+    g = torch.Generator().manual_seed(3)
+    val = torch.rand(max(n, 1), generator=g)[:n]
+    d_idx, d_val = idx.to(dev), val.to(dev)
+    # Sum
+    out = torch.empty(n_rays, device=dev)
+    capi.call("seg_sum_fwd", d_val, d_idx, out, n_rays)
+    torch.testing.assert_close(out.cpu(), K.seg_sum_fwd(val, idx), rtol=1e-5, atol=1e-6)
+    dsum = torch.randn(n_rays, generator=g)
+    dval = torch.zeros(n, device=dev)
+    capi.call("seg_sum_bwd", dsum.to(dev), d_idx, dval, n_rays)
+    assert torch.equal(dval.cpu(), K.seg_sum_bwd(dsum, idx, n))
+    # SumVec (3 channels = RGB, and 16)
+    for vec in (3, 16):
+        v = torch.rand(n, vec, generator=g)
+        out = torch.empty(n_rays, vec, device=dev)
+        capi.call("seg_sum_vec_fwd", v.to(dev), d_idx, out, n_rays, vec)
+        torch.testing.assert_close(out.cpu(), K.seg_sum_fwd(v, idx), rtol=1e-5, atol=1e-6)
+        ds = torch.randn(n_rays, vec, generator=g)
+        dv = torch.zeros(n, vec, device=dev)
+        capi.call("seg_sum_vec_bwd", ds.to(dev), d_idx, dv, n_rays, vec)
+        assert torch.equal(dv.cpu(), K.seg_sum_bwd(ds, idx, n))
+    # AccumulateSum, both flavours, fwd + bwd
+    for inc in (0, 1):
+        out = torch.zeros(n, device=dev)
+        capi.call("seg_scan_fwd", d_val, d_idx, out, n_rays, inc)
+        torch.testing.assert_close(out.cpu(), K.seg_scan_fwd(val, idx, inc), rtol=1e-5, atol=1e-6)
+        gsum = torch.randn(n, generator=g)
+        out = torch.zeros(n, device=dev)
+        capi.call("seg_scan_bwd", gsum.to(dev), d_idx, out, n_rays, inc)
+        torch.testing.assert_close(out.cpu(), K.seg_scan_bwd(gsum, idx, inc), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("n_rays,max_len", [(64, 40), (700, 300)])
+def test_weight_var(capi, dev, n_rays, max_len):
+    idx, n = util.ragged_bounds(n_rays, max_len, seed=21)
+    g = torch.Generator().manual_seed(8)
+    w = torch.rand(n, generator=g) * 0.1
+    out = torch.empty(n_rays, device=dev)
+    capi.call("weight_var_fwd", w.to(dev), idx.to(dev), out, n_rays)
+    torch.testing.assert_close(out.cpu(), K.weight_var_fwd(w, idx), rtol=2e-4, atol=1e-6)
+    dv = torch.randn(n_rays, generator=g)
+    dw = torch.zeros(n, device=dev)
+    capi.call("weight_var_bwd", w.to(dev), idx.to(dev), dv.to(dev), dw, n_rays)
+    ref = K.weight_var_bwd(w, idx, dv)
+    torch.testing.assert_close(dw.cpu(), ref, rtol=2e-4, atol=1e-4 * ref.abs().max().item())
+
+
+# --------------------------------------------------------------------------------- scatter ------
+
+
+def test_scatter(capi, dev):
+    n_rays, E, C = 500, 50, 16
+    idx, n = util.ragged_bounds(n_rays, 120, seed=2)
+    g = torch.Generator().manual_seed(12)
+    emb_idx = torch.randint(0, E, (n_rays,), generator=g).to(torch.int32)
+    ref_all = K.scatter_idx(n, idx, emb_idx)
+    all_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+    capi.call("scatter_idx", idx.to(dev), emb_idx.to(dev), all_idx, n_rays)
+    assert torch.equal(all_idx.cpu(), ref_all)
+    emb = torch.randn(E, C, generator=g)
+    to_add = torch.randn(n, C, generator=g)
+    out = torch.empty(n, C, device=dev)
+    capi.call("scatter_add_fwd", emb.to(dev), all_idx, to_add.to(dev), out, n, C)
+    assert torch.equal(out.cpu(), K.scatter_add_fwd(emb, ref_all, to_add))
+    dsum = torch.randn(n, C, generator=g)
+    demb = torch.full((E, C), 3.0, device=dev)  # must be overwritten, not accumulated into
+    capi.call("scatter_add_bwd", all_idx, dsum.to(dev), demb, n, E, C)
+    ref = K.scatter_add_bwd(ref_all, dsum, E)
+    torch.testing.assert_close(demb.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+# --------------------------------------------------------------------------------- sampler ------
+
+
+def _rays(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(n, 3, generator=g) * 0.3
+    d = torch.randn(n, 3, generator=g) * 2.0
+    return o, d
+
+
+@pytest.mark.parametrize("S,step,train", [(1024, 1.0 / 256, True), (1024, 1.0 / 256, False),
+                                          (128, 4.0 / 128, True), (100, 0.05, True)])
+def test_sample_rays(capi, dev, S, step, train):
+    from oracle import ref_render as R
+    n = 97
+    o, d = _rays(n, 1)
+    g = torch.Generator().manual_seed(5)
+    noise = (torch.rand(n, S, generator=g) - 0.5 + 1.0) if train else None
+    pts, dirs, dt, t, bounds = R.get_samples(o, d, noise, S, step)
+    N = n * S
+    o_pts, o_dirs = torch.empty(N, 3, device=dev), torch.empty(N, 3, device=dev)
+    o_dt, o_t = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    o_b = torch.empty(n, 2, dtype=torch.int32, device=dev)
+    capi.call("sample_rays", o.to(dev), d.to(dev), noise.to(dev) if train else None, o_pts,
+              o_dirs, o_dt, o_t, o_b, n, S, step)
+    assert torch.equal(o_b.cpu(), bounds)
+    torch.testing.assert_close(o_dirs.cpu(), dirs, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(o_t.cpu(), t, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(o_pts.cpu(), pts, rtol=1e-5, atol=2e-6)
+    # dt is a difference of nearby points (quirk Q7): absolute error ~ ulp(|p|), relative to dt ~1e-4
+    torch.testing.assert_close(o_dt.cpu(), dt, rtol=1e-3, atol=2e-6)
+    assert (o_dt.cpu().reshape(n, S)[:, 0] == 0).all()
