@@ -146,6 +146,7 @@ def test_composite_fwd_bwd(capi, dev, n_rays, max_len, with_dw):
     g_logit, g_rgb = torch.zeros(n, device=dev), torch.zeros(n, 3, device=dev)
     capi.call("composite_bwd", d_feat, 16, dv(rgb), dv(dt), dv(t), dv(idx), dv(bg), o_w, o_lt,
               dv(d_c), dv(d_d), dv(d_w) if with_dw else None, g_logit, g_rgb, n_rays, 3.0, 1e-2)
-    torch.testing.assert_close(g_rgb.cpu(), rgb.grad, rtol=1e-4, atol=1e-7)
+    # d_rgb = w * dC and alpha = 1 - exp(-s) carries an absolute error of ~ulp(1) = 6e-8 on both sides
+    torch.testing.assert_close(g_rgb.cpu(), rgb.grad, rtol=1e-4, atol=1e-6)
     ref = logit.grad
     torch.testing.assert_close(g_logit.cpu(), ref, rtol=1e-3, atol=1e-4 * ref.abs().max().item())

@@ -17,6 +17,12 @@ def _to(dev, *ts):
 # --------------------------------------------------------------------------------- hash grid ----
 
 
+def _assert_hash_values(got, ref):
+    """Same FMA order and the same f32-then-f16 rounding on both sides: bit-exact is expected
+    (the kernel pins the f32 rounding so hipcc cannot fuse it into v_fma_mixlo_f16)."""
+    assert torch.equal(got, ref), ((got != ref).sum().item(), ref.numel())
+
+
 @pytest.mark.parametrize("L,F,log2_T,stride_mode", [
     (16, 2, 19, "ref"),      # the reference's compile-time configuration (overlapping levels, Q2)
     (4, 2, 19, "ref"),       # BASELINE config C1
@@ -40,12 +46,8 @@ def test_hash_fwd_parity(capi, dev, L, F, log2_T, stride_mode):
               fld["stride"])
     # hash rows: integer work, bit-exact
     assert torch.equal(idx.cpu(), ref_idx)
-    # values: same FMA order + same f16 rounding -> expected bit-exact; allow 1 f16 ulp on <=1e-4
     got = out.cpu()
-    diff = (got - ref).abs()
-    exact = (diff == 0).float().mean().item()
-    assert exact >= 1.0 - 1e-4, exact
-    assert (diff <= util.f16_ulp(ref)).all()
+    _assert_hash_values(got, ref)
     # channel-major output layout gives the same numbers
     out_t = torch.empty(L * F, n, device=dev)
     capi.call("hash_fwd", d_pts, d_tab, d_pr, d_bias, d_mul, out_t, 1, n, None, n, L, F, T,
@@ -65,7 +67,7 @@ def test_hash_fwd_non_pow2_T_and_empty(capi, dev):
     idx = torch.empty(n, L, 8, dtype=torch.int32, device=dev)
     capi.call("hash_fwd", *d, out, L * F, 1, idx, n, L, F, T, T * F)
     assert torch.equal(idx.cpu(), ref_idx)
-    assert torch.equal(out.cpu(), ref)
+    _assert_hash_values(out.cpu(), ref)
     capi.call("hash_fwd", *d, out, L * F, 1, None, 0, L, F, T, T * F)  # n == 0 is a no-op
     with pytest.raises(capi.F2NError):
         capi.call("hash_fwd", *d, out, L * F, 1, None, n, L, 3, T, T * F)  # F=3 unsupported
@@ -185,7 +187,8 @@ def test_segment_ops(capi, dev, n_rays, max_len):
         gsum = torch.randn(n, generator=g)
         out = torch.zeros(n, device=dev)
         capi.call("seg_scan_bwd", gsum.to(dev), d_idx, out, n_rays, inc)
-        torch.testing.assert_close(out.cpu(), K.seg_scan_bwd(gsum, idx, inc), rtol=1e-4, atol=2e-5)
+        # randn inputs cancel: the error scales with sum|x| over the run (<= ~1e3), not with the result
+        torch.testing.assert_close(out.cpu(), K.seg_scan_bwd(gsum, idx, inc), rtol=1e-4, atol=2e-4)
 
 
 @pytest.mark.parametrize("n_rays,max_len", [(64, 40), (700, 300)])
