@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- rendered rays/sec (forward + backward) of the F2-NeRF hot path on MI355X.
+
+One "step" = one full 800x800 synthetic view (640 000 rays) pushed through
+Renderer::render(TRAIN) + loss + backward in 65 536-ray chunks (BASELINE.json configs[1]:
+128 samples/ray, L=16 hash levels, F=2, T=2^19, one GPU).  The optimiser step is excluded, as in
+BASELINE.md.  Rays, step noise inputs (drawn on device per chunk, as the reference does), ground
+truth colours and all parameters are resident in HBM before the timed region starts.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): rays shard embarrassingly -- every rank
+renders its own view per step (weak scaling); the only collective is one RCCL all-reduce per step of
+{sum of squared error, value count} for the global PSNR.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     -- the dominant hand-written kernel's algorithmic bytes / its hipEvent-timed duration
+  cpu_baseline -- the CPU oracle (a port of the reference arranged as the reference is) timed on
+                  this box's host cores on a bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--levels", type=int, default=16)
+    ap.add_argument("--channels", type=int, default=2)
+    ap.add_argument("--log2-table", type=int, default=19)
+    ap.add_argument("--chunk", type=int, default=65536)
+    ap.add_argument("--regime", choices=["dense", "terminating"], default="dense")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=2048)
+    ap.add_argument("--n-images", type=int, default=50)
+    return ap.parse_args()
+
+
+def fox_like_poses(n, seed=2022):
+    """n camera poses on a 200-degree arc of radius 1 around the origin, heights U[-0.2, 0.2],
+    looking at the origin (OpenGL convention: -z forward, y up), then normalised the way the
+    reference normalises a dataset (src/dataset.cpp:77-86: centre = mean position, scale = max
+    distance from it)."""
+    g = torch.Generator().manual_seed(seed)
+    ang = torch.linspace(-100.0, 100.0, n) * math.pi / 180.0
+    pos = torch.stack([torch.cos(ang), torch.sin(ang), torch.rand(n, generator=g) * 0.4 - 0.2], 1)
+    zc = pos / pos.norm(dim=1, keepdim=True)          # camera z axis points away from the target
+    up = torch.tensor([0.0, 0.0, 1.0]).expand(n, 3)
+    xc = torch.cross(up, zc, dim=1)
+    xc = xc / xc.norm(dim=1, keepdim=True)
+    yc = torch.cross(zc, xc, dim=1)
+    center = pos.mean(0)
+    radius = (pos - center).norm(dim=1).max()
+    pos_n = (pos - center) / radius
+    return torch.cat([torch.stack([xc, yc, zc], 2), pos_n.unsqueeze(2)], 2)  # [n,3,4]
+
+
+def view_rays(H, pose, intr, h, w):
+    ii, jj = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=pose.device),
+                            torch.arange(w, dtype=torch.float32, device=pose.device), indexing="ij")
+    ij = torch.stack([ii.reshape(-1), jj.reshape(-1)], -1)
+    o, d = H.get_rays_from_pose(pose.unsqueeze(0), intr.unsqueeze(0), ij)
+    return o.contiguous(), d.contiguous()
+
+
+def algorithmic_bytes(kernel, L, F, S):
+    """bytes one unit must move if every byte is touched once."""
+    if kernel == "hash_fwd":   # per sample: xyz in, 8 corners x F f16 per level, L*F f32 out
+        return 12 + 16 * L * F + 4 * L * F
+    if kernel == "hash_bwd":   # per sample: xyz + L*F f32 grads in, 8 corners x F f32 RMW counted once
+        return 12 + 4 * L * F + 16 * L * F
+    if kernel == "density_march":  # per ray (dense regime): o,d in, S x (noise + 8 corners x F f16 x L), count out
+        return 24 + S * (4 + 16 * L * F) + 4
+    raise KeyError(kernel)
+
+
+def cpu_baseline(args, n_rays):
+    """The oracle = CPU port arranged as the reference is (torch-CPU ATen ops + C/OpenMP restatement
+    of the 14 CUDA kernels), same workload shape, bounded ray count."""
+    from oracle import kernels as K
+    from oracle import ref_render as R
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    K.set_num_threads(cores)
+    g = torch.Generator().manual_seed(2022)
+    torch.manual_seed(2022)
+    ren = R.Renderer(args.n_images, L=args.levels, F=args.channels, log2_T=args.log2_table,
+                     S=args.samples, step=4.0 / args.samples, gen=g, feat_init="trained")
+    ren.scene_field.parallel_bwd = True
+    if args.regime == "terminating":
+        with torch.no_grad():
+            ren.scene_field.mlp.bias[0] = 8.0
+    poses = fox_like_poses(args.n_images)
+    intr = torch.tensor([[1111.1, 0, args.width / 2], [0, 1111.1, args.height / 2], [0, 0, 1.0]])
+    pix = torch.randint(0, args.height * args.width, (n_rays,), generator=g)
+    ij = torch.stack([pix // args.width, pix % args.width], 1)
+    o, d = R.get_rays_from_pose(poses[0:1], intr[None], ij)
+    gt = torch.rand(n_rays, 3, generator=g)
+    emb = torch.zeros(n_rays, dtype=torch.int32)
+    times = []
+    for it in range(3):
+        noise = torch.rand(n_rays, args.samples, generator=g) + 0.5
+        bg = torch.rand(n_rays, 3, generator=g)
+        ren.zero_grad()
+        t0 = time.perf_counter()
+        loss, _, _, _ = R.train_loss(ren, o, d, emb, gt, noise, bg, 0.0)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        if sum(times) > 40:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": n_rays / best, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": "%d random rays of view 0, S=%d L=%d F=%d T=2^%d, fwd+bwd, best of %d after 1 warm-up"
+                      % (n_rays, args.samples, args.levels, args.channels, args.log2_table,
+                         max(1, len(times) - 1))}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+
+    pkg = importlib.import_module("f2-nerf_amd")
+    H = pkg.load_host()
+    H.manual_seed(2022)          # reference main.cpp:11; identical parameters on every rank
+    torch.manual_seed(2022)
+    S, L, F = args.samples, args.levels, args.channels
+    ren = H.Renderer(args.n_images, n_levels=L, n_channels=F, log2_table=args.log2_table,
+                     max_samples=S, step=4.0 / S)
+    params = ren.named_parameters()
+    with torch.no_grad():
+        # "trained-like" table: N(0, 0.1^2) exercises the f16 range and real gradients
+        params["scene_field.feat_pool"].normal_(0.0, 0.1)
+        if args.regime == "terminating":
+            params["scene_field.mlp.bias"][0] = 8.0
+    torch.manual_seed(1000 + rank)   # per-rank randomness for noise / background from here on
+
+    poses = fox_like_poses(args.n_images).to(dev)
+    intr = torch.tensor([[1111.1, 0, args.width / 2], [0, 1111.1, args.height / 2], [0, 0, 1.0]],
+                        device=dev)
+    n_rays_view = args.height * args.width
+    total_steps = args.warmup + args.steps
+    # inputs resident in HBM before timing: rays + ground truth of every view this rank renders
+    views = []
+    for s in range(total_steps):
+        v = (s * world + rank) % args.n_images
+        o, d = view_rays(H, poses[v], intr, args.height, args.width)
+        gt = torch.rand(n_rays_view, 3, device=dev)
+        emb = torch.full((n_rays_view,), v, dtype=torch.int32, device=dev)
+        views.append((o, d, gt, emb))
+
+    def run_step(view):
+        o, d, gt, emb = view
+        ren.zero_grad()
+        sq = torch.zeros((), device=dev, dtype=torch.float64)
+        n_val = 0
+        n_samples = 0
+        for lo in range(0, n_rays_view, args.chunk):
+            hi = min(lo + args.chunk, n_rays_view)
+            loss, sq_err, nv, ns = ren.train_step(o[lo:hi], d[lo:hi], emb[lo:hi], gt[lo:hi], 0.0)
+            sq += sq_err.double()
+            n_val += nv
+            n_samples += ns
+        stat = torch.stack([sq, torch.tensor(float(n_val), device=dev, dtype=torch.float64)])
+        if dist is not None:
+            dist.all_reduce(stat)   # the only collective: {sum sq err, count} -> global PSNR
+        return stat, n_samples
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        run_step(views[s])
+    barrier()
+    H.kernel_timer_enable(True)
+    H.kernel_timer_collect()
+    t0 = time.perf_counter()
+    n_samples_total = 0
+    stat = None
+    for s in range(args.warmup, total_steps):
+        stat, ns = run_step(views[s])
+        n_samples_total += ns
+    barrier()
+    elapsed = time.perf_counter() - t0
+    H.kernel_timer_enable(False)
+    timings = H.kernel_timer_collect()
+
+    t_max = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    mse = float(stat[0] / stat[1])
+    psnr = 20.0 * math.log10(1.0 / math.sqrt(mse))   # reference train_manager.cpp:96
+
+    if rank == 0:
+        rays_total = n_rays_view * args.steps * world
+        kernels = {}
+        for name, (launches, total_ms, units) in timings.items():
+            b = algorithmic_bytes(name, L, F, S)
+            kernels[name] = {
+                "launches": launches, "avg_ms": total_ms / max(launches, 1),
+                "units_per_launch": units / max(launches, 1),
+                "algorithmic_bytes_per_unit": b,
+                "achieved_GBs": (units * b) / (total_ms * 1e-3) / 1e9 if total_ms > 0 else None,
+                "share_of_step": total_ms * 1e-3 / (elapsed * 1.0),
+            }
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
+        roofline = None
+        if dom:
+            a = kernels[dom]["achieved_GBs"]
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None}
+        out = {
+            "metric": "rendered rays/sec (fwd+bwd) at 800x800",
+            "value": rays_total / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "ngp_fox-like synthetic views %dx%d, %d samples/ray, L=%d F=%d T=2^%d, "
+                                   "%d-ray chunks, TRAIN render + loss + backward (optimizer excluded)"
+                                   % (args.height, args.width, S, L, F, args.log2_table, args.chunk),
+                       "regime": args.regime, "rays_per_step_per_gpu": n_rays_view,
+                       "samples_per_ray_kept": n_samples_total / (n_rays_view * args.steps),
+                       "sharding": "one view per rank per step, RCCL all-reduce of {sq_err, n} only"},
+            "psnr_vs_random_gt": psnr,
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, args.cpu_rays)
+                out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
+                out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(),
+                                       "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

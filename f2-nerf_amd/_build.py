@@ -115,7 +115,7 @@ def _torch_flags():
     ldflags = [
         "-L" + tlib, "-Wl,-rpath," + tlib, "-Wl,-rpath,$ORIGIN",
         "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
-        "-L" + LIB_DIR, "-lf2nerf_hip",
+        "-L" + LIB_DIR, "-lf2nerf_hip", "-L" + os.path.join(ROCM, "lib"), "-lamdhip64",
     ]
     return inc, cflags, ldflags
 

@@ -1,0 +1,239 @@
+// hash_3d_anchored.cpp -- host half of the hash-grid field (see hash_3d_anchored.hpp).
+// Behaviour follows reference src/hash_3d_anchored.cpp:19-114 (construction, query, optimiser
+// groups) and src/hash_3d_anchored.cu:150-218 (the autograd Function around the kernels).
+#include "hash_3d_anchored.hpp"
+
+#include "kernel_timer.hpp"
+
+#include <cmath>
+
+using Tensor = torch::Tensor;
+
+TORCH_LIBRARY(dec_hash3d_anchored, m)
+{
+  m.class_<Hash3DAnchoredInfo>("Hash3DAnchoredInfo").def(torch::init());
+}
+
+namespace
+{
+
+// x = p inside the unit ball, (2 - 1/|p|) p/|p| outside; |p| == 0 gives NaN like the reference's
+// mask expression.  Backward = the Jacobian-vector product autograd would assemble from it.
+class ContractFn : public torch::autograd::Function<ContractFn>
+{
+public:
+  static torch::autograd::variable_list forward(torch::autograd::AutogradContext * ctx, Tensor points)
+  {
+    points = f2n::dev_f32(points, "Hash3DAnchored::query points");
+    TORCH_CHECK(points.dim() == 2 && points.size(1) == 3, "points must be [n, 3]");
+    Tensor x = torch::empty_like(points);
+    f2n::check(
+      f2n_contract_fwd(
+        points.data_ptr<float>(), x.data_ptr<float>(), points.size(0), f2n::current_stream(points)),
+      "f2n_contract_fwd");
+    ctx->save_for_backward({points});
+    return {x};
+  }
+
+  static torch::autograd::variable_list backward(
+    torch::autograd::AutogradContext * ctx, torch::autograd::variable_list grad_output)
+  {
+    Tensor points = ctx->get_saved_variables()[0];
+    Tensor dx = f2n::dev_f32(grad_output[0], "contraction grad");
+    Tensor dp = torch::empty_like(points);
+    f2n::check(
+      f2n_contract_bwd(
+        points.data_ptr<float>(), dx.data_ptr<float>(), dp.data_ptr<float>(), points.size(0),
+        f2n::current_stream(points)),
+      "f2n_contract_bwd");
+    return {dp};
+  }
+};
+
+bool is_prime(int64_t x)
+{
+  if (x < 2) return false;
+  for (int64_t i = 2; i * i <= x; i++)
+    if (x % i == 0) return false;
+  return true;
+}
+
+}  // namespace
+
+Hash3DAnchored::Hash3DAnchored(const Hash3DAnchoredOptions & opt) : options_(opt)
+{
+  const int64_t L = opt.n_levels, F = opt.n_channels;
+  TORCH_CHECK(L >= 1 && L <= F2N_MAX_LEVELS, "n_levels out of range");
+  TORCH_CHECK(F == 1 || F == 2 || F == 4 || F == 8, "n_channels must be 1, 2, 4 or 8");
+  const auto fopt = f2n::float_on(opt.device);
+
+  pool_size_ = (int)((int64_t(1) << opt.log2_table) * L);
+  local_size_ = (int)(((pool_size_ / L) >> 4) << 4);  // rows per level, reference .cpp:57-58
+  level_stride_ = opt.level_stride > 0 ? opt.level_stride : local_size_;
+  TORCH_CHECK(level_stride_ % F == 0, "level_stride must be a multiple of n_channels");
+  // rows needed so the last level's window [stride*(L-1), stride*(L-1) + T*F) stays in bounds
+  const int64_t need_rows = (level_stride_ * (L - 1) + int64_t(local_size_) * F + F - 1) / F;
+  const int64_t rows = std::max<int64_t>(pool_size_, need_rows);
+
+  // (U[0,1) * 0.2 - 1) * 1e-4, reference .cpp:24
+  feat_pool_ = (torch::rand({rows, F}, fopt) * .2f - 1.f) * 1e-4f;
+  feat_pool_.requires_grad_(true);
+
+  // 3L random primes in [2^28, 2^30), drawn on the CPU generator like the reference (.cpp:29-48)
+  std::vector<int32_t> primes;
+  const auto cpu_int = torch::TensorOptions().dtype(torch::kInt32).device(torch::kCPU);
+  while ((int64_t)primes.size() < 3 * L) {
+    const int v = torch::randint(1 << 28, 1 << 30, {1}, cpu_int).item<int>();
+    if (is_prime(v)) primes.push_back(v);
+  }
+  prim_pool_ = torch::from_blob(primes.data(), {L, 3}, cpu_int).clone().to(opt.device).contiguous();
+  bias_pool_ = (torch::rand({L, 3}, fopt) * 1000.f + 100.f).contiguous();
+
+  // per-level scale, reference hash_3d_anchored.cu:72-73, evaluated in f32 with glibc exp2f
+  std::vector<float> mul((size_t)L);
+  for (int64_t l = 0; l < L; l++) {
+    const float e = (L > 1) ? ((10.f - 3.f) * float(l) / float(L - 1) + 3.f) : 3.f;
+    mul[(size_t)l] = exp2f(e);
+  }
+  level_mul_ =
+    torch::from_blob(mul.data(), {L}, torch::TensorOptions().dtype(torch::kFloat32)).clone().to(
+      opt.device);
+
+  mlp_ = torch::nn::Linear(L * F, opt.mlp_out_dim);
+  mlp_->to(opt.device);
+
+  register_parameter("feat_pool", feat_pool_);
+  register_parameter("prim_pool", prim_pool_, false);
+  register_parameter("bias_pool", bias_pool_);
+  register_module("mlp", mlp_);
+}
+
+Tensor Hash3DAnchored::table_f16()
+{
+  TORCH_CHECK(feat_pool_.is_cuda(), "Hash3DAnchored: feat_pool must live on the GPU");
+  const void * src = feat_pool_.data_ptr();
+  const uint32_t ver = feat_pool_._version();
+  if (!feat_pool_f16_.defined() || src != shadow_src_ || ver != shadow_version_ ||
+      feat_pool_f16_.numel() != feat_pool_.numel()) {
+    Tensor master = feat_pool_.detach().contiguous();
+    if (!feat_pool_f16_.defined() || feat_pool_f16_.numel() != master.numel() ||
+        feat_pool_f16_.device() != master.device())
+      feat_pool_f16_ = torch::empty(master.sizes(), master.options().dtype(torch::kFloat16));
+    f2n::check(
+      f2n_table_to_f16(
+        master.data_ptr<float>(), reinterpret_cast<uint16_t *>(feat_pool_f16_.data_ptr()),
+        master.numel(), f2n::current_stream(master)),
+      "f2n_table_to_f16");
+    shadow_src_ = src;
+    shadow_version_ = ver;
+  }
+  return feat_pool_f16_;
+}
+
+Tensor Hash3DAnchored::table_for(const Tensor & feat_pool)
+{
+  if (feat_pool.data_ptr() == feat_pool_.data_ptr()) return table_f16();
+  // a table other than the module's own parameter: cast it on the spot, as the reference does
+  Tensor master = f2n::dev_f32(feat_pool.detach(), "feat_pool");
+  Tensor t16 = torch::empty(master.sizes(), master.options().dtype(torch::kFloat16));
+  f2n::check(
+    f2n_table_to_f16(
+      master.data_ptr<float>(), reinterpret_cast<uint16_t *>(t16.data_ptr()), master.numel(),
+      f2n::current_stream(master)),
+    "f2n_table_to_f16");
+  return t16;
+}
+
+std::pair<Tensor, Tensor> Hash3DAnchored::density_head() const
+{
+  return {mlp_->weight.detach().select(0, 0).contiguous(),
+          mlp_->bias.detach().slice(0, 0, 1).contiguous()};
+}
+
+Tensor Hash3DAnchored::query(const Tensor & points)
+{
+  auto info = torch::make_intrusive<Hash3DAnchoredInfo>();
+  info->hash3d_ = this;
+
+  // scene contraction (reference .cpp:79-82: eight ATen launches) as one kernel each way
+  Tensor x = ContractFn::apply(points)[0];
+
+  Tensor feat =
+    torch::autograd::Hash3DAnchoredFunction::apply(x, feat_pool_, torch::IValue(info))[0];
+  return mlp_->forward(feat);
+}
+
+std::vector<torch::optim::OptimizerParamGroup> Hash3DAnchored::optim_param_groups(float lr)
+{
+  // Adam, betas (0.9, 0.99), eps 1e-15; weight decay 1e-6 on the MLP only (reference .cpp:90-114)
+  std::vector<torch::optim::OptimizerParamGroup> groups;
+  auto table_opt = std::make_unique<torch::optim::AdamOptions>(lr);
+  table_opt->betas(std::make_tuple(0.9, 0.99)).eps(1e-15);
+  groups.emplace_back(std::vector<Tensor>{feat_pool_}, std::move(table_opt));
+
+  auto mlp_opt = std::make_unique<torch::optim::AdamOptions>(lr);
+  mlp_opt->betas(std::make_tuple(0.9, 0.99)).eps(1e-15).weight_decay(1e-6);
+  groups.emplace_back(mlp_->parameters(), std::move(mlp_opt));
+  return groups;
+}
+
+namespace torch::autograd
+{
+
+variable_list Hash3DAnchoredFunction::forward(
+  AutogradContext * ctx, Tensor points, Tensor feat_pool, IValue hash3d_info)
+{
+  auto info = hash3d_info.toCustomClass<Hash3DAnchoredInfo>();
+  Hash3DAnchored * field = info->hash3d_;
+  ctx->saved_data["hash3d_info"] = hash3d_info;
+  points = f2n::dev_f32(points, "Hash3DAnchoredFunction points");
+  TORCH_CHECK(points.dim() == 2 && points.size(1) == 3, "points must be [n, 3]");
+  ctx->save_for_backward({points, feat_pool});
+
+  const int64_t n = points.size(0);
+  const int L = (int)field->options_.n_levels, F = (int)field->options_.n_channels;
+  Tensor table16 = field->table_for(feat_pool);
+  // f32 tensor holding f16-rounded values: the reference's out_feat.to(kFloat32), fused
+  Tensor out = torch::empty({n, (int64_t)L * F}, points.options());
+  f2n::ScopedKernelTimer timer("hash_fwd", f2n::current_stream(points), (double)n);
+  f2n::check(
+    f2n_hash_fwd(
+      points.data_ptr<float>(), reinterpret_cast<const uint16_t *>(table16.data_ptr()),
+      field->prim_pool_.data_ptr<int32_t>(), field->bias_pool_.data_ptr<float>(),
+      field->level_mul_.data_ptr<float>(), out.data_ptr<float>(), (int64_t)L * F, 1, nullptr, n, L,
+      F, (uint32_t)field->local_size_, field->level_stride_, f2n::current_stream(points)),
+    "f2n_hash_fwd");
+  return {out};
+}
+
+variable_list Hash3DAnchoredFunction::backward(AutogradContext * ctx, variable_list grad_output)
+{
+  auto info = ctx->saved_data["hash3d_info"].toCustomClass<Hash3DAnchoredInfo>();
+  Hash3DAnchored * field = info->hash3d_;
+  auto saved = ctx->get_saved_variables();
+  Tensor & points = saved[0];
+  Tensor & feat_pool = saved[1];
+
+  const int64_t n = points.size(0);
+  const int L = (int)field->options_.n_levels, F = (int)field->options_.n_channels;
+  const float grad_scale = 128.f;  // reference hash_3d_anchored.cu:190
+
+  Tensor grad_in = f2n::dev_f32(grad_output[0], "Hash3DAnchoredFunction grad");
+  Tensor table16 = field->table_for(feat_pool);
+  // points need a gradient only for pose optimisation; training rays are data
+  const bool want_points = ctx->needs_input_grad(0);
+  Tensor points_grad = want_points ? torch::empty({n, 3}, points.options()) : Tensor();
+  Tensor embeds_grad = torch::zeros_like(feat_pool);
+  f2n::ScopedKernelTimer timer("hash_bwd", f2n::current_stream(points), (double)n);
+  f2n::check(
+    f2n_hash_bwd(
+      points.data_ptr<float>(), reinterpret_cast<const uint16_t *>(table16.data_ptr()),
+      field->prim_pool_.data_ptr<int32_t>(), field->bias_pool_.data_ptr<float>(),
+      field->level_mul_.data_ptr<float>(), grad_in.data_ptr<float>(), (int64_t)L * F, 1,
+      embeds_grad.data_ptr<float>(), want_points ? points_grad.data_ptr<float>() : nullptr, n, L, F,
+      (uint32_t)field->local_size_, field->level_stride_, grad_scale, f2n::current_stream(points)),
+    "f2n_hash_bwd");
+  return {points_grad, embeds_grad, Tensor()};
+}
+
+}  // namespace torch::autograd

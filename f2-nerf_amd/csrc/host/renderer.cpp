@@ -1,0 +1,263 @@
+// renderer.cpp -- see renderer.hpp.  Arithmetic per reference src/renderer.cpp:18-197.
+#include "renderer.hpp"
+
+#include "kernel_timer.hpp"
+
+#include "ragged_ops.hpp"
+#include "rays.hpp"
+
+using Tensor = torch::Tensor;
+
+Renderer::Renderer(int n_images, const RendererOptions & opt) : options_(opt)
+{
+  pts_sampler_ = std::make_shared<PtsSampler>(opt.sampler);
+
+  scene_field_ = std::make_shared<Hash3DAnchored>(opt.field);
+  register_module("scene_field", scene_field_);
+
+  shader_ = std::make_shared<SHShader>(opt.field.device);
+  register_module("shader", shader_);
+
+  app_emb_ = torch::randn({n_images, 16}, f2n::float_on(opt.field.device)) * .1f;
+  app_emb_.requires_grad_(true);
+  register_parameter("app_emb", app_emb_);
+}
+
+RenderResult Renderer::render(
+  const Tensor & rays_o, const Tensor & rays_d, const Tensor & emb_idx, RunningMode mode)
+{
+  return render(rays_o, rays_d, emb_idx, mode, Tensor(), Tensor());
+}
+
+RenderResult Renderer::render(
+  const Tensor & rays_o, const Tensor & rays_d, const Tensor & emb_idx, RunningMode mode,
+  const Tensor & noise_in, const Tensor & bg_in)
+{
+  const int64_t n_rays = rays_o.size(0);
+  const auto fopt = f2n::float_on(rays_o.device());
+  Tensor noise = noise_in.defined() ? noise_in
+                                    : pts_sampler_->draw_noise(n_rays, mode, rays_o.device());
+  Tensor bg_color = bg_in.defined() ? bg_in
+                    : (mode == RunningMode::TRAIN) ? torch::rand({n_rays, 3}, fopt)
+                                                   : torch::ones({n_rays, 3}, fopt) * .5f;
+  if (n_rays <= 0) {
+    last_n_samples_ = 0;
+    return {bg_color, torch::zeros({n_rays}, fopt), torch::full({n_rays}, 512.f, fopt), Tensor()};
+  }
+  const bool rays_need_grad =
+    torch::GradMode::is_enabled() && (rays_o.requires_grad() || rays_d.requires_grad());
+  RenderResult res = (options_.fused && !rays_need_grad)
+                       ? render_fused(rays_o, rays_d, emb_idx, mode, noise, bg_color)
+                       : render_op_by_op(rays_o, rays_d, emb_idx, mode, noise, bg_color);
+  if (options_.check_finite) CHECK(std::isfinite(res.colors.mean().item<float>()));
+  return res;
+}
+
+// ---- fused path ----------------------------------------------------------------------------------
+
+RenderResult Renderer::render_fused(
+  const Tensor & rays_o_raw, const Tensor & rays_d_raw, const Tensor & emb_idx, RunningMode mode,
+  const Tensor & noise_raw, const Tensor & bg_color)
+{
+  Tensor rays_o = f2n::dev_f32(rays_o_raw.detach(), "rays_o");
+  Tensor rays_d = f2n::dev_f32(rays_d_raw.detach(), "rays_d");
+  Tensor noise = noise_raw.defined() ? f2n::dev_f32(noise_raw, "noise") : Tensor();
+  const int n_rays = (int)rays_o.size(0);
+  const int S = pts_sampler_->options_.max_samples;
+  const float step = pts_sampler_->options_.step;
+  TORCH_CHECK(!noise.defined() || noise.numel() == (int64_t)n_rays * S, "noise shape");
+  const auto fopt = rays_o.options();
+  const auto iopt = f2n::int_on(rays_o.device());
+  void * stream = f2n::current_stream(rays_o);
+  Hash3DAnchored & field = *scene_field_;
+  const int L = (int)field.options_.n_levels, F = (int)field.options_.n_channels;
+
+  SampleResultFlex kept;
+  {
+    // First pass (renderer.cpp:58-90): density only, never differentiated by the loss.
+    torch::NoGradGuard no_grad;
+    Tensor table16 = field.table_f16();
+    auto head = field.density_head();
+    Tensor counts = torch::empty({n_rays}, iopt);
+    {
+      f2n::ScopedKernelTimer timer("density_march", stream, (double)n_rays);
+      f2n::check(
+      f2n_density_march(
+        rays_o.data_ptr<float>(), rays_d.data_ptr<float>(), f2n::fptr(noise),
+        reinterpret_cast<const uint16_t *>(table16.data_ptr()), field.prim_pool_.data_ptr<int32_t>(),
+        field.bias_pool_.data_ptr<float>(), field.level_mul_.data_ptr<float>(),
+        head.first.data_ptr<float>(), head.second.data_ptr<float>(), counts.data_ptr<int32_t>(),
+        n_rays, S, step, L, F, (uint32_t)field.local_size_, field.level_stride_,
+        options_.early_stop_trans, 3.f, stream),
+      "f2n_density_march");
+    }
+    kept.pts_idx_bounds = torch::empty({n_rays, 2}, iopt);
+    Tensor total = torch::empty({1}, iopt);
+    f2n::check(
+      f2n_bounds_from_counts(
+        counts.data_ptr<int32_t>(), kept.pts_idx_bounds.data_ptr<int32_t>(),
+        total.data_ptr<int32_t>(), n_rays, stream),
+      "f2n_bounds_from_counts");
+    const int64_t n_kept = total.item<int>();  // the one host sync of the fused path (sizes tensors)
+    last_n_samples_ = n_kept;
+    kept.pts = torch::empty({n_kept, 3}, fopt);
+    kept.dirs = torch::empty({n_kept, 3}, fopt);
+    kept.dt = torch::empty({n_kept}, fopt);
+    kept.t = torch::empty({n_kept}, fopt);
+    f2n::check(
+      f2n_sample_compact(
+        rays_o.data_ptr<float>(), rays_d.data_ptr<float>(), f2n::fptr(noise),
+        kept.pts_idx_bounds.data_ptr<int32_t>(), kept.pts.data_ptr<float>(),
+        kept.dirs.data_ptr<float>(), kept.dt.data_ptr<float>(), kept.t.data_ptr<float>(), n_rays, S,
+        step, stream),
+      "f2n_sample_compact");
+  }
+  return shade_and_composite(kept, emb_idx, mode, bg_color);
+}
+
+// Second pass on the survivors (renderer.cpp:92-118).
+RenderResult Renderer::shade_and_composite(
+  const SampleResultFlex & kept, const Tensor & emb_idx, RunningMode mode, const Tensor & bg_color)
+{
+  const int64_t n_kept = kept.pts.size(0);
+  Tensor scene_feat = scene_field_->query(kept.pts);  // [n, 16]: col 0 density logit, 1.. shading
+
+  Tensor shading_feat = torch::cat(
+    {torch::ones({n_kept, 1}, scene_feat.options()),
+     scene_feat.index({Slc(), Slc(1, torch::indexing::None)})},
+    1);
+  if (mode == RunningMode::TRAIN) {
+    Tensor all_emb_idx = CustomOps::ScatterIdx((int)n_kept, kept.pts_idx_bounds, emb_idx);
+    shading_feat = CustomOps::ScatterAdd(app_emb_, all_emb_idx, shading_feat);
+  }
+  Tensor sampled_colors = shader_->query(shading_feat, kept.dirs);
+
+  f2n::CompositeOut out =
+    f2n::composite(scene_feat, sampled_colors, kept.dt, kept.t, kept.pts_idx_bounds, bg_color);
+  return {out.colors, out.depths, out.weights, kept.pts_idx_bounds};
+}
+
+// ---- op-by-op path (the reference's own sequence on the drop-in operators) -----------------------
+
+RenderResult Renderer::render_op_by_op(
+  const Tensor & rays_o, const Tensor & rays_d, const Tensor & emb_idx, RunningMode mode,
+  const Tensor & noise, const Tensor & bg_color)
+{
+  const int64_t n_rays = rays_o.size(0);
+  const int64_t S = pts_sampler_->options_.max_samples;
+  const bool rays_need_grad =
+    torch::GradMode::is_enabled() && (rays_o.requires_grad() || rays_d.requires_grad());
+  SampleResultFlex all = rays_need_grad ? pts_sampler_->get_samples_aten(rays_o, rays_d, noise)
+                                        : pts_sampler_->get_samples(rays_o, rays_d, noise);
+
+  auto density_act = [](const Tensor & x) {
+    return torch::autograd::TruncExp::apply(x - 3.f)[0];
+  };
+
+  SampleResultFlex kept;
+  {
+    Tensor scene_feat = scene_field_->query(all.pts);
+    Tensor density = density_act(scene_feat.index({Slc(), Slc(0, 1)}));
+    Tensor sec = density.index({Slc(), 0}) * all.dt;
+    Tensor acc = FlexOps::AccumulateSum(sec, all.pts_idx_bounds, false);
+    Tensor mask = torch::exp(-acc) > options_.early_stop_trans;
+    Tensor mask_idx = torch::where(mask)[0];
+    kept.pts = all.pts.index({mask_idx}).contiguous();
+    kept.dirs = all.dirs.index({mask_idx}).contiguous();
+    kept.dt = all.dt.index({mask_idx}).contiguous();
+    kept.t = all.t.index({mask_idx}).contiguous();
+    Tensor num = mask.reshape({n_rays, S}).sum(1);
+    Tensor cum = torch::cumsum(num, 0);
+    kept.pts_idx_bounds = torch::stack({cum - num, cum}, 1).to(torch::kInt32).contiguous();
+  }
+  last_n_samples_ = kept.pts.size(0);
+
+  Tensor scene_feat = scene_field_->query(kept.pts);
+  Tensor density = density_act(scene_feat.index({Slc(), Slc(0, 1)}));
+  Tensor shading_feat = torch::cat(
+    {torch::ones_like(scene_feat.index({Slc(), Slc(0, 1)})),
+     scene_feat.index({Slc(), Slc(1, torch::indexing::None)})},
+    1);
+  if (mode == RunningMode::TRAIN) {
+    Tensor all_emb_idx =
+      CustomOps::ScatterIdx((int)kept.pts.size(0), kept.pts_idx_bounds, emb_idx);
+    shading_feat = CustomOps::ScatterAdd(app_emb_, all_emb_idx, shading_feat);
+  }
+  Tensor sampled_colors = shader_->query(shading_feat, kept.dirs);
+  Tensor sampled_t = (kept.t + 1e-2f).contiguous();
+  Tensor sec = density.index({Slc(), 0}) * kept.dt;
+  Tensor alphas = 1.f - torch::exp(-sec);
+  Tensor idx = kept.pts_idx_bounds;
+  Tensor trans = torch::exp(-FlexOps::AccumulateSum(sec, idx, false));
+  Tensor weights = trans * alphas;
+  Tensor last_trans = torch::exp(-FlexOps::Sum(sec, idx));
+  Tensor colors = FlexOps::Sum(weights.unsqueeze(-1) * sampled_colors, idx) +
+                  last_trans.unsqueeze(-1) * bg_color;
+  Tensor depths = FlexOps::Sum(weights * sampled_t, idx) / (1.f - last_trans + 1e-4f);
+  return {colors, depths, weights, idx};
+}
+
+// ---- whole-image helpers -------------------------------------------------------------------------
+
+std::tuple<Tensor, Tensor> Renderer::render_all_rays(
+  const Tensor & rays_o, const Tensor & rays_d, const int batch_size)
+{
+  const int64_t n_rays = rays_d.size(0);
+  std::vector<Tensor> colors, depths;
+  for (int64_t lo = 0; lo < n_rays; lo += batch_size) {
+    const int64_t hi = std::min<int64_t>(lo + batch_size, n_rays);
+    RenderResult r = render(
+      rays_o.index({Slc(lo, hi)}).contiguous(), rays_d.index({Slc(lo, hi)}).contiguous(), Tensor(),
+      RunningMode::VALIDATE);
+    colors.push_back(r.colors);
+    depths.push_back(r.depths.reshape({-1, 1}));
+  }
+  return {torch::cat(colors, 0), torch::cat(depths, 0)};
+}
+
+std::tuple<Tensor, Tensor> Renderer::render_image(
+  const Tensor & pose, const Tensor & intrinsic, const int h, const int w, const int batch_size)
+{
+  const auto fopt = f2n::float_on(pose.device());
+  auto grid = torch::meshgrid({torch::arange(h, fopt), torch::arange(w, fopt)}, "ij");
+  Tensor ij = torch::stack({grid[0].reshape({-1}), grid[1].reshape({-1})}, -1);
+  Rays rays = get_rays_from_pose(pose.unsqueeze(0), intrinsic.unsqueeze(0), ij);
+  auto [colors, depths] = render_all_rays(rays.origins, rays.dirs, batch_size);
+  colors = colors.reshape({h, w, 3}).clip(0.f, 1.f);
+  depths = depths.reshape({h, w, 1}).repeat({1, 1, 3});
+  return {colors, depths};
+}
+
+std::vector<torch::optim::OptimizerParamGroup> Renderer::optim_param_groups(float lr)
+{
+  std::vector<torch::optim::OptimizerParamGroup> groups;
+  for (auto & g : scene_field_->optim_param_groups(lr)) groups.emplace_back(g);
+  for (auto & g : shader_->optim_param_groups(lr)) groups.emplace_back(g);
+  auto opt = std::make_unique<torch::optim::AdamOptions>(lr);
+  opt->betas(std::make_tuple(0.9, 0.99)).eps(1e-15).weight_decay(1e-6);
+  groups.emplace_back(std::vector<Tensor>{app_emb_}, std::move(opt));
+  return groups;
+}
+
+// ---- training-step harness -----------------------------------------------------------------------
+
+f2n::TrainStepResult f2n::train_step(
+  Renderer & renderer, const Tensor & rays_o, const Tensor & rays_d, const Tensor & emb_idx,
+  const Tensor & gt_colors, float var_loss_weight, const Tensor & noise, const Tensor & bg_color,
+  bool run_backward)
+{
+  RenderResult res =
+    renderer.render(rays_o, rays_d, emb_idx, RunningMode::TRAIN, noise, bg_color);
+  Tensor err = res.colors - gt_colors;
+  Tensor color_loss = torch::sqrt(err.square() + 1e-4f).mean();
+  Tensor var = CustomOps::WeightVar(res.weights, res.idx_start_end);
+  Tensor var_loss = (var + 1e-2f).sqrt().mean();
+  Tensor loss = color_loss + var_loss * var_loss_weight;
+  TrainStepResult out;
+  out.loss = loss.detach();
+  out.sq_err_sum = err.detach().square().sum();
+  out.n_values = err.numel();
+  out.n_samples = renderer.last_n_samples_;
+  if (run_backward && loss.requires_grad()) loss.backward();
+  return out;
+}

@@ -1,0 +1,107 @@
+// renderer.hpp -- Renderer: sampler + scene field + shader + per-image appearance embedding, and
+// the volumetric render of a batch of rays.
+//
+// Public surface of reference src/renderer.hpp:15-49 (RenderResult, Renderer::render /
+// render_all_rays / render_image / optim_param_groups); registered names "scene_field", "shader",
+// "app_emb" kept so a reference checkpoint (renderer.pt) loads.
+//
+// render() has two implementations of the same arithmetic (reference src/renderer.cpp:33-123):
+//   fused (default)   one wavefront-per-ray march finds each ray's kept prefix (early termination
+//                     in-kernel), a scan turns counts into bounds, one kernel emits the compacted
+//                     samples, and compositing is one kernel per direction;
+//   op-by-op          the reference's own sequence (sample all, query all, AccumulateSum, where,
+//                     4x index, query survivors, Sum...) on the drop-in operators.  Used when rays
+//                     carry gradients (pose optimisation) and as the cross-check of the fused path.
+#pragma once
+
+#include <memory>
+#include <tuple>
+#include <vector>
+
+#include "hash_3d_anchored.hpp"
+#include "points_sampler.hpp"
+#include "sh_shader.hpp"
+
+struct RenderResult
+{
+  using Tensor = torch::Tensor;
+  Tensor colors;
+  Tensor depths;
+  Tensor weights;
+  Tensor idx_start_end;
+};
+
+struct RendererOptions
+{
+  Hash3DAnchoredOptions field;
+  PtsSamplerOptions sampler;
+  bool fused = true;
+  float early_stop_trans = 1e-4f;  // renderer.cpp:68
+  bool check_finite = false;       // the reference's CHECK(isfinite(colors.mean())) host sync
+};
+
+class Renderer : public torch::nn::Module
+{
+  using Tensor = torch::Tensor;
+
+public:
+  explicit Renderer(int n_images, const RendererOptions & opt = {});
+
+  RenderResult render(
+    const Tensor & rays_o, const Tensor & rays_d, const Tensor & emb_idx, RunningMode mode);
+
+  // Same, with the device-side randomness supplied: `noise` [n_rays, max_samples] (undefined =
+  // draw as the mode dictates), `bg_color` [n_rays, 3] (undefined = rand in TRAIN, 0.5 otherwise).
+  RenderResult render(
+    const Tensor & rays_o, const Tensor & rays_d, const Tensor & emb_idx, RunningMode mode,
+    const Tensor & noise, const Tensor & bg_color);
+
+  std::tuple<Tensor, Tensor> render_all_rays(
+    const Tensor & rays_o, const Tensor & rays_d, const int batch_size);
+
+  std::tuple<Tensor, Tensor> render_image(
+    const torch::Tensor & pose, const torch::Tensor & intrinsic, const int h, const int w,
+    const int batch_size);
+
+  std::vector<torch::optim::OptimizerParamGroup> optim_param_groups(float lr);
+
+  RendererOptions options_;
+  std::shared_ptr<PtsSampler> pts_sampler_;
+  std::shared_ptr<Hash3DAnchored> scene_field_;
+  std::shared_ptr<SHShader> shader_;
+  Tensor app_emb_;
+
+  int64_t last_n_samples_ = 0;  // survivors of the most recent render() (bench bookkeeping)
+
+private:
+  RenderResult render_fused(
+    const Tensor & rays_o, const Tensor & rays_d, const Tensor & emb_idx, RunningMode mode,
+    const Tensor & noise, const Tensor & bg_color);
+  RenderResult render_op_by_op(
+    const Tensor & rays_o, const Tensor & rays_d, const Tensor & emb_idx, RunningMode mode,
+    const Tensor & noise, const Tensor & bg_color);
+  RenderResult shade_and_composite(
+    const SampleResultFlex & kept, const Tensor & emb_idx, RunningMode mode,
+    const Tensor & bg_color);
+};
+
+namespace f2n
+{
+
+// The loss / backward segment of the reference's training loop
+// (reference src/main_functions/train_manager.cpp:76-107 minus the optimiser step):
+// render(TRAIN), Charbonnier colour loss, scheduled weight-variance loss, backward().
+struct TrainStepResult
+{
+  Tensor loss;        // scalar
+  Tensor sq_err_sum;  // scalar: sum over rays and channels of (pred - gt)^2
+  int64_t n_values;   // n_rays * 3
+  int64_t n_samples;  // surviving samples in this step
+};
+
+TrainStepResult train_step(
+  Renderer & renderer, const Tensor & rays_o, const Tensor & rays_d, const Tensor & emb_idx,
+  const Tensor & gt_colors, float var_loss_weight, const Tensor & noise, const Tensor & bg_color,
+  bool run_backward);
+
+}  // namespace f2n

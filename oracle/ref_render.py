@@ -133,12 +133,26 @@ def weight_var(w, idx):
 # ------------------------------------------------------------------------------------------------
 
 
+_SMALL_PRIMES = None
+
+
 def _is_prime(x):
-    i = 2
-    while i * i <= x:
-        if x % i == 0:
+    """Trial division (hash_3d_anchored.cpp:29-35) restricted to prime divisors <= sqrt(2^30)."""
+    global _SMALL_PRIMES
+    if _SMALL_PRIMES is None:
+        sieve = bytearray([1]) * 32769
+        sieve[0:2] = b"\x00\x00"
+        for i in range(2, 182):
+            if sieve[i]:
+                sieve[i * i::i] = bytearray(len(sieve[i * i::i]))
+        _SMALL_PRIMES = [i for i in range(32769) if sieve[i]]
+    if x < 2:
+        return False
+    for q in _SMALL_PRIMES:
+        if q * q > x:
+            break
+        if x % q == 0:
             return False
-        i += 1
     return True
 
 

@@ -4,13 +4,7 @@ import torch
 from oracle import kernels as K
 
 
-def is_prime(x):
-    i = 2
-    while i * i <= x:
-        if x % i == 0:
-            return False
-        i += 1
-    return True
+from oracle.ref_render import _is_prime as is_prime  # noqa: E402
 
 
 def make_field(L=16, F=2, log2_T=19, level_stride=None, seed=0, init="trained"):
