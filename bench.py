@@ -89,13 +89,35 @@ def algorithmic_bytes(kernel, L, F, S):
     raise KeyError(kernel)
 
 
+def usable_cores():
+    """Host cores this process may actually run on: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def cpu_baseline(args, n_rays):
     """The oracle = CPU port arranged as the reference is (torch-CPU ATen ops + C/OpenMP restatement
     of the 14 CUDA kernels), same workload shape, bounded ray count."""
     from oracle import kernels as K
     from oracle import ref_render as R
 
-    cores = os.cpu_count() or 1
+    cores = int(os.environ.get("F2N_CPU_THREADS", "0")) or min(usable_cores(), 64)
     torch.set_num_threads(cores)
     K.set_num_threads(cores)
     g = torch.Generator().manual_seed(2022)

@@ -185,20 +185,30 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
       [](Renderer & r, const Tensor & o, const Tensor & d, const c10::optional<Tensor> & emb_idx,
          const std::string & mode, const c10::optional<Tensor> & noise,
          const c10::optional<Tensor> & bg) {
-        return result_tuple(
-          r.render(o, d, opt_tensor(emb_idx), parse_mode(mode), opt_tensor(noise), opt_tensor(bg)));
+        RenderResult res;
+        {
+          py::gil_scoped_release no_gil;
+          res = r.render(
+            o, d, opt_tensor(emb_idx), parse_mode(mode), opt_tensor(noise), opt_tensor(bg));
+        }
+        return result_tuple(res);
       },
       py::arg("rays_o"), py::arg("rays_d"), py::arg("emb_idx") = py::none(),
       py::arg("mode") = "validate", py::arg("noise") = py::none(), py::arg("bg_color") = py::none())
-    .def("render_all_rays", &Renderer::render_all_rays)
-    .def("render_image", &Renderer::render_image)
+    .def("render_all_rays", &Renderer::render_all_rays, py::call_guard<py::gil_scoped_release>())
+    .def("render_image", &Renderer::render_image, py::call_guard<py::gil_scoped_release>())
     .def(
       "train_step",
       [](Renderer & r, const Tensor & o, const Tensor & d, const Tensor & emb_idx, const Tensor & gt,
          float var_loss_weight, const c10::optional<Tensor> & noise,
          const c10::optional<Tensor> & bg, bool backward) {
-        auto out = f2n::train_step(
-          r, o, d, emb_idx, gt, var_loss_weight, opt_tensor(noise), opt_tensor(bg), backward);
+        f2n::TrainStepResult out;
+        {
+          // loss.backward() runs the autograd engine, which must not be entered holding the GIL
+          py::gil_scoped_release no_gil;
+          out = f2n::train_step(
+            r, o, d, emb_idx, gt, var_loss_weight, opt_tensor(noise), opt_tensor(bg), backward);
+        }
         return py::make_tuple(out.loss, out.sq_err_sum, out.n_values, out.n_samples);
       },
       py::arg("rays_o"), py::arg("rays_d"), py::arg("emb_idx"), py::arg("gt_colors"),
@@ -232,7 +242,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
       "torch::optim::Adam over optim_param_groups(lr) (reference train_manager.cpp:55)");
 
   py::class_<AdamHandle>(m, "Adam")
-    .def("step", [](AdamHandle & h) { h.opt->step(); })
+    .def("step", [](AdamHandle & h) { h.opt->step(); }, py::call_guard<py::gil_scoped_release>())
     .def("zero_grad", [](AdamHandle & h) { h.opt->zero_grad(); })
     .def("n_groups", [](AdamHandle & h) { return h.opt->param_groups().size(); })
     .def("set_lr", [](AdamHandle & h, double lr) {

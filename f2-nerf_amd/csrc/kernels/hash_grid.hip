@@ -10,6 +10,8 @@
 // table is one level (T*F*2 bytes: 2 MiB at the reference size), which an XCD's 4 MiB L2 holds.
 #include "hash_grid.hiph"
 
+#include <cstdlib>
+
 namespace
 {
 
@@ -136,6 +138,81 @@ __global__ __launch_bounds__(F2N_BLOCK) void hash_bwd_kernel(
   }
 }
 
+// v2 ("sliced"): the table gradient is built in LDS, not with global atomics.
+//
+// Scattered global float atomics run at ~2e10 requests/s on MI355X (each lane's add is its own
+// 64-B request to the memory side; MI355X_MICROARCH.md "Global float atomics"), which made v1 the
+// dominant kernel of a training step.  Here a workgroup owns one (level, slice) pair, a slice being
+// kSliceFloats/F consecutive table rows held as f32 accumulators in 128 KiB of LDS.  It walks ALL
+// points of its sample partition, recomputes the 8 hashed rows (integer VALU work, the points stream
+// from L2 because the co-resident workgroups of an XCD walk the same range together) and applies only
+// the corners that land in its slice with ds_add_f32.  At the end the slice is added into the global
+// gradient with contiguous atomics (256 B per wave instruction = the full atomic rate; atomics
+// because the reference's level windows overlap, quirk Q2).  The hash work is repeated n_slices
+// times (32x at the reference size) -- it is cheap next to 2e9 scattered atomics.
+constexpr int kSliceFloats = 32768;  // 128 KiB of f32 accumulators
+constexpr int kSliceBlock = 1024;
+
+template <int F, bool POW2>
+__global__ __launch_bounds__(kSliceBlock) void hash_bwd_sliced_kernel(
+  const float * __restrict__ pts, const int32_t * __restrict__ primes,
+  const float * __restrict__ bias, const float * __restrict__ mul,
+  const float * __restrict__ grad_out, int64_t g_ld_point, int64_t g_ld_chan,
+  float * __restrict__ table_grad, int64_t n, uint32_t T, int64_t level_stride, float grad_scale,
+  float inv_scale, int n_parts)
+{
+  __shared__ float acc[kSliceFloats];
+  constexpr uint32_t kRows = kSliceFloats / F;  // rows per slice (power of two)
+  const uint32_t slice = blockIdx.x;
+  const int l = blockIdx.y;
+  const int part = blockIdx.z;
+  const uint32_t row_lo = slice * kRows;
+
+  for (int i = threadIdx.x; i < kSliceFloats; i += kSliceBlock) acc[i] = 0.f;
+  __syncthreads();
+
+  const LevelParams lp = load_level(primes, bias, mul, l);
+  const int64_t per = (n + n_parts - 1) / n_parts;
+  const int64_t p_begin = per * part;
+  const int64_t p_end = (p_begin + per < n) ? p_begin + per : n;
+  for (int64_t p = p_begin + threadIdx.x; p < p_end; p += kSliceBlock) {
+    const float x = pts[3 * p + 0], y = pts[3 * p + 1], z = pts[3 * p + 2];
+    uint32_t row[8];
+    float w[8];
+    corner_rows_and_weights<POW2>(x, y, z, lp, T, row, w);
+    bool hit = false;
+#pragma unroll
+    for (int d = 0; d < 8; d++) hit |= ((row[d] - row_lo) < kRows);
+    if (hit) {
+      const float * g = grad_out + p * g_ld_point + (int64_t)(l * F) * g_ld_chan;
+      float gk[F];
+#pragma unroll
+      for (int k = 0; k < F; k++) gk[k] = round_f16(g[k * g_ld_chan] * grad_scale);
+#pragma unroll
+      for (int d = 0; d < 8; d++) {
+        const uint32_t local = row[d] - row_lo;
+        if (local < kRows) {
+#pragma unroll
+          for (int k = 0; k < F; k++) {
+            const float c = round_f16(gk[k] * w[d]);
+            if (c != 0.f) atomicAdd(&acc[local * F + k], c);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // flush: slice rows [row_lo, row_lo + kRows) of level l, clipped to T
+  float * gbase = table_grad + level_stride * l + (int64_t)row_lo * F;
+  const uint32_t rows_here = (row_lo + kRows <= T) ? kRows : (T > row_lo ? T - row_lo : 0u);
+  const int n_flush = (int)rows_here * F;
+  for (int i = threadIdx.x; i < n_flush; i += kSliceBlock) {
+    const float v = acc[i];
+    if (v != 0.f) atomicAdd(gbase + i, v * inv_scale);
+  }
+}
+
 // ---------------------------------------------------------------------------- contraction ------
 
 __global__ __launch_bounds__(F2N_BLOCK) void contract_fwd_kernel(
@@ -257,12 +334,37 @@ extern "C" int f2n_hash_bwd(
   if (!(grad_scale > 0.f) || m != 0.5f) return F2N_E_INVALID_ARG;  // power of two only
   if (n == 0) return F2N_OK;
   hipStream_t s = (hipStream_t)stream;
+  const bool p2 = is_pow2(T);
+  const float inv = 1.f / grad_scale;
+
+  // Training case (no point gradient) on a big batch: LDS-sliced accumulation.  The hash work is
+  // repeated once per slice, so it only pays while the slice count stays moderate.
+  const int64_t rows_per_slice = kSliceFloats / F;
+  const int64_t n_slices = ((int64_t)T + rows_per_slice - 1) / rows_per_slice;
+  const char * force = getenv("F2N_HASH_BWD");  // "atomic" | "sliced": A/B switch for profiling
+  bool sliced = !pts_grad && n_slices <= 64 && n >= 32768;
+  if (force && !pts_grad && n_slices <= 1024) sliced = (force[0] == 's');
+  if (sliced) {
+    // enough sample partitions to put >= 2 workgroups on every CU when levels x slices is small
+    int n_parts = 1;
+    while ((int64_t)L * n_slices * n_parts < 512 && (n / (n_parts * 2)) >= 65536) n_parts *= 2;
+    const dim3 grid((unsigned)n_slices, (unsigned)L, (unsigned)n_parts), block(kSliceBlock);
+#define F2N_BWD_SLICED(P2)                                                                        \
+  hipLaunchKernelGGL(                                                                             \
+    (hash_bwd_sliced_kernel<FF, P2>), grid, block, 0, s, pts, primes, bias, mul, grad_out,        \
+    g_ld_point, g_ld_chan, table_grad, n, T, level_stride, grad_scale, inv, n_parts)
+    F2N_DISPATCH_F(F, {
+      if (p2) F2N_BWD_SLICED(true);
+      else F2N_BWD_SLICED(false);
+    })
+#undef F2N_BWD_SLICED
+    return f2n_launch_status();
+  }
+
   if (pts_grad) {
     if (hipMemsetAsync(pts_grad, 0, sizeof(float) * 3 * n, s) != hipSuccess) return F2N_E_LAUNCH;
   }
   const dim3 grid(f2n_div_up(n, F2N_BLOCK), (unsigned)L), block(F2N_BLOCK);
-  const bool p2 = is_pow2(T);
-  const float inv = 1.f / grad_scale;
 #define F2N_BWD_LAUNCH(P2, PG)                                                                    \
   hipLaunchKernelGGL(                                                                             \
     (hash_bwd_kernel<FF, P2, PG>), grid, block, 0, s, pts, table_f16, primes, bias, mul, grad_out, \

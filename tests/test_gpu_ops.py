@@ -107,6 +107,32 @@ def test_hash_bwd_parity(capi, dev, L, F, log2_T, stride_mode, pts_grad):
     assert (tg.cpu() - 2 * ref_tg).abs().max().item() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("L,F,T,stride,n", [
+    (16, 2, 1 << 19, None, 40000),     # reference size: 32 slices per level, overlapping levels
+    (4, 2, 1 << 19, None, 70000),      # few (level, slice) pairs -> sample partitions
+    (3, 4, 3000, 3000 * 4, 33000),     # non power-of-two T, one partial slice
+    (2, 8, 1 << 13, (1 << 13) * 8, 33000),
+])
+def test_hash_bwd_sliced_path(capi, dev, L, F, T, stride, n):
+    """Big batches without a point gradient take the LDS-sliced kernel; same contributions, the
+    f32 sums in another order."""
+    log2_T = max(1, (T - 1).bit_length())
+    fld = util.make_field(L, F, log2_T, stride, seed=77)
+    st = fld["stride"]
+    pts = util.ball_points(n, seed=16)
+    g = torch.Generator().manual_seed(14)
+    grad = torch.randn(n, L * F, generator=g) * 1e-3
+    numel = fld["table"].numel()
+    ref_tg, _ = K.hash_bwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad,
+                           numel, L, F, T, st, 128.0, parallel=True)
+    d = _to(dev, pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad)
+    tg = torch.zeros(numel, device=dev)
+    capi.call("hash_bwd", *d, L * F, 1, tg, None, n, L, F, T, st, 128.0)
+    scale = ref_tg.abs().max().item()
+    assert (tg.cpu() - ref_tg).abs().max().item() <= 2e-5 * scale
+    assert ((tg.cpu() - ref_tg).norm() / ref_tg.norm()).item() < 1e-6
+
+
 def test_table_cast(capi, dev):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1 << 16, generator=g) * 0.1
