@@ -191,7 +191,7 @@ def main():
     # inputs resident in HBM before timing: rays + ground truth of every view this rank renders
     views = []
     for s in range(total_steps):
-        v = (s * world + rank) % args.n_images
+        v = pkg.sharding.view_for(s, rank, world, args.n_images)
         o, d = view_rays(H, poses[v], intr, args.height, args.width)
         gt = torch.rand(n_rays_view, 3, device=dev)
         emb = torch.full((n_rays_view,), v, dtype=torch.int32, device=dev)
@@ -209,9 +209,8 @@ def main():
             sq += sq_err.double()
             n_val += nv
             n_samples += ns
-        stat = torch.stack([sq, torch.tensor(float(n_val), device=dev, dtype=torch.float64)])
-        if dist is not None:
-            dist.all_reduce(stat)   # the only collective: {sum sq err, count} -> global PSNR
+        # the only collective of the path: {sum sq err, count} -> global PSNR (RCCL all-reduce)
+        stat = pkg.sharding.reduce_error_stats(sq, n_val, dist)
         return stat, n_samples
 
     def barrier():
@@ -239,8 +238,7 @@ def main():
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
-    mse = float(stat[0] / stat[1])
-    psnr = 20.0 * math.log10(1.0 / math.sqrt(mse))   # reference train_manager.cpp:96
+    psnr, mse = pkg.sharding.psnr_from_stats(stat)   # reference train_manager.cpp:96
 
     if rank == 0:
         rays_total = n_rays_view * args.steps * world

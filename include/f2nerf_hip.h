@@ -126,14 +126,14 @@ int f2n_scatter_add_bwd(
 /* PtsSampler::get_samples (about 20 ATen launches) -- src/points_sampler.cpp:20-64.
  *   noise   [n_rays, S] f32 step multipliers (TRAIN: U[0.5,1.5)), or NULL for all-ones (VALIDATE)
  *   outputs pts [n_rays*S, 3], dirs [n_rays*S, 3], dt [n_rays*S], t [n_rays*S], bounds [n_rays,2]
- *   S = MAX_SAMPLE_PER_RAY (1024), step = SAMPLE_L (1/256) in the reference (points_sampler.hpp:15,39) */
+ *   S = MAX_SAMPLE_PER_RAY (1024), step = SAMPLE_L (1/256) in the reference (src/points_sampler.hpp:15,39) */
 int f2n_sample_rays(
   const float * rays_o, const float * rays_d, const float * noise, float * pts, float * dirs,
   float * dt, float * t, int32_t * bounds, int n_rays, int S, float step, void * stream);
 
 /* Early-stop pass of Renderer::render fused into one march -- src/renderer.cpp:58-90 together with
- * points_sampler.cpp:20-64, hash_3d_anchored.cpp:79-86 (contraction, hash encode, row 0 of the
- * Linear) and CustomOps.cpp:10-14 (TruncExp fwd).  One wavefront walks one ray in 64-sample
+ * src/points_sampler.cpp:20-64, src/hash_3d_anchored.cpp:79-86 (contraction, hash encode, row 0 of the
+ * Linear) and src/CustomOps/CustomOps.cpp:10-14 (TruncExp fwd).  One wavefront walks one ray in 64-sample
  * strides and stops at the first stride whose transmittance exp(-sum sigma*dt) falls to
  * <= t_thresh; kept[r] = number of leading samples with T > t_thresh (the mask of :68 is a prefix).
  *   w0 [L*F] = mlp.weight[0, :], b0 = mlp.bias[0]; density = exp(w0.enc + b0 - density_shift) */
@@ -143,12 +143,12 @@ int f2n_density_march(
   int32_t * kept, int n_rays, int S, float step, int L, int F, uint32_t T, int64_t level_stride,
   float t_thresh, float density_shift, void * stream);
 
-/* cumsum of the per-ray counts -> bounds (renderer.cpp:76-83).  total[0] = sum(kept).
+/* cumsum of the per-ray counts -> bounds (src/renderer.cpp:76-83).  total[0] = sum(kept).
  * Single-workgroup scan; n_rays <= 2^24. */
 int f2n_bounds_from_counts(
   const int32_t * kept, int32_t * bounds, int32_t * total, int n_rays, void * stream);
 
-/* where(mask) + the four index() gathers (renderer.cpp:69-74) without materialising the dense
+/* where(mask) + the four index() gathers (src/renderer.cpp:69-74) without materialising the dense
  * sample arrays: re-derives the first (end-start) samples of each ray straight into the compacted
  * outputs pts/dirs [n_kept,3], dt/t [n_kept]. */
 int f2n_sample_compact(
@@ -157,7 +157,7 @@ int f2n_sample_compact(
 
 /* ------------------------------------------------------------------ compositing (rows A7, A8) - */
 
-/* renderer.cpp:93,107-118 as one pass per ray:
+/* src/renderer.cpp:93,107-118 as one pass per ray:
  *   sigma = exp(logit - density_shift); s = sigma*dt; alpha = 1-exp(-s); T = exp(-excl_scan(s));
  *   w = T*alpha; T_last = exp(-sum s); C = sum w*rgb + T_last*bg; D = sum w*(t+t_shift)/(1-T_last+1e-4)
  *   logit element i at logit[i*logit_ld] (column 0 of the [n,16] field output: logit_ld = 16)
@@ -168,7 +168,7 @@ int f2n_composite_fwd(
   float * last_trans, int n_rays, float density_shift, float t_shift, void * stream);
 
 /* Backward of the above = FlexSum/FlexSumVec/FlexAccumulateSum backward kernels plus the ATen
- * element-wise backward and TruncExp::backward (CustomOps.cpp:16-20: exp(clamp(x,-100,5))).
+ * element-wise backward and TruncExp::backward (src/CustomOps/CustomOps.cpp:16-20: exp(clamp(x,-100,5))).
  *   in : d_colors [n_rays,3], d_depths [n_rays], d_weights [n] (NULL = zeros)
  *   out: d_logit [n] (dense), d_rgb [n,3] */
 int f2n_composite_bwd(
