@@ -28,9 +28,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 
 # -ffp-contract=off: the kernels spell out every fused multiply-add (parity with the oracle).
+# -fno-slp-vectorize: SLP pairs FMAs of two weight rows into v_pk_fma_f32, whose SGPR operand pairs
+#   must then be assembled with s_mov/v_readlane -- 25 % more instructions in the fused MLP kernels.
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-    "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
+    "-fno-slp-vectorize", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
 ]
 
 

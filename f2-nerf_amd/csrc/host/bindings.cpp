@@ -225,6 +225,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         return d;
       })
     .def("set_fused", [](Renderer & r, bool f) { r.options_.fused = f; })
+    .def("set_fused_shade", [](Renderer & r, bool f) { r.options_.fused_shade = f; })
     .def_readonly("last_n_samples", &Renderer::last_n_samples_)
     .def_property_readonly("scene_field", [](Renderer & r) { return r.scene_field_; })
     .def_property_readonly("shader", [](Renderer & r) { return r.shader_; })

@@ -150,17 +150,19 @@ std::pair<Tensor, Tensor> Hash3DAnchored::density_head() const
           mlp_->bias.detach().slice(0, 0, 1).contiguous()};
 }
 
-Tensor Hash3DAnchored::query(const Tensor & points)
+Tensor Hash3DAnchored::encode(const Tensor & points)
 {
   auto info = torch::make_intrusive<Hash3DAnchoredInfo>();
   info->hash3d_ = this;
 
   // scene contraction (reference .cpp:79-82: eight ATen launches) as one kernel each way
   Tensor x = ContractFn::apply(points)[0];
+  return torch::autograd::Hash3DAnchoredFunction::apply(x, feat_pool_, torch::IValue(info))[0];
+}
 
-  Tensor feat =
-    torch::autograd::Hash3DAnchoredFunction::apply(x, feat_pool_, torch::IValue(info))[0];
-  return mlp_->forward(feat);
+Tensor Hash3DAnchored::query(const Tensor & points)
+{
+  return mlp_->forward(encode(points));
 }
 
 std::vector<torch::optim::OptimizerParamGroup> Hash3DAnchored::optim_param_groups(float lr)

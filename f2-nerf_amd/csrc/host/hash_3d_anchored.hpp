@@ -37,6 +37,10 @@ public:
 
   Tensor query(const Tensor & points);
 
+  // contraction + hash encode only (no Linear): [n, L*F], stored channel-major.  The Renderer's
+  // fused path feeds this straight into the fused per-sample network kernel.
+  Tensor encode(const Tensor & points);
+
   // Row 0 of mlp_ (weight [L*F], bias [1]) as contiguous device tensors: the density head the fused
   // ray march evaluates in-kernel.
   std::pair<Tensor, Tensor> density_head() const;

@@ -227,6 +227,84 @@ public:
   }
 };
 
+// channel-major [C, n] storage behind a logical [n, C] tensor (no copy when it already is)
+Tensor as_channel_major(const Tensor & t)
+{
+  if (t.dim() == 2 && t.stride(0) == 1 && t.stride(1) == t.size(0)) return t.t();
+  return t.t().contiguous();
+}
+
+class ShadeFn : public torch::autograd::Function<ShadeFn>
+{
+public:
+  static variable_list forward(
+    AutogradContext * ctx, Tensor enc, Tensor dirs, Tensor sample_img, Tensor w_h, Tensor b_h,
+    Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor app_emb)
+  {
+    TORCH_CHECK(enc.is_cuda() && enc.scalar_type() == torch::kFloat32 && enc.dim() == 2, "enc");
+    const int64_t n = enc.size(0);
+    const int C = (int)enc.size(1);
+    Tensor enc_cm = as_channel_major(enc);  // [C, n] contiguous
+    dirs = f2n::dev_f32(dirs.detach(), "shade dirs");
+    // "no embedding" arrives as empty tensors (undefined tensors cannot pass through apply())
+    const bool use_emb = sample_img.defined() && app_emb.defined() && sample_img.numel() > 0 &&
+                         app_emb.numel() > 0;
+    if (use_emb) sample_img = f2n::dev_i32(sample_img, "shade sample_img");
+    w_h = f2n::dev_f32(w_h, "w_h");
+    b_h = f2n::dev_f32(b_h, "b_h");
+    w1 = f2n::dev_f32(w1, "w1");
+    b1 = f2n::dev_f32(b1, "b1");
+    w2 = f2n::dev_f32(w2, "w2");
+    b2 = f2n::dev_f32(b2, "b2");
+    Tensor emb = use_emb ? f2n::dev_f32(app_emb, "app_emb") : Tensor();
+    TORCH_CHECK(
+      w_h.size(0) == 16 && w_h.size(1) == C && w1.size(0) == 64 && w1.size(1) == 32 &&
+        w2.size(0) == 3 && w2.size(1) == 64,
+      "shade: layer shapes must be 16xC, 64x32, 3x64");
+    Tensor logit = torch::empty({n}, enc.options()), rgb = torch::empty({n, 3}, enc.options());
+    f2n::check(
+      f2n_shade_fwd(
+        enc_cm.data_ptr<float>(), C, dirs.data_ptr<float>(), use_emb ? f2n::iptr(sample_img) : nullptr,
+        f2n::fptr(w_h), f2n::fptr(b_h), f2n::fptr(w1), f2n::fptr(b1), f2n::fptr(w2), f2n::fptr(b2),
+        f2n::fptr(emb), logit.data_ptr<float>(), rgb.data_ptr<float>(), n,
+        f2n::current_stream(enc_cm)),
+      "f2n_shade_fwd");
+    ctx->save_for_backward({enc_cm, dirs, use_emb ? sample_img : Tensor(), w_h, b_h, w1, b1, w2, b2, emb});
+    return {logit, rgb};
+  }
+
+  static variable_list backward(AutogradContext * ctx, variable_list grad_output)
+  {
+    auto sv = ctx->get_saved_variables();
+    Tensor &enc_cm = sv[0], &dirs = sv[1], &sample_img = sv[2], &w_h = sv[3], &b_h = sv[4],
+           &w1 = sv[5], &b1 = sv[6], &w2 = sv[7], &b2 = sv[8], &emb = sv[9];
+    const int C = (int)enc_cm.size(0);
+    const int64_t n = enc_cm.size(1);
+    auto opt = enc_cm.options();
+    Tensor d_logit = grad_output[0].defined() ? f2n::dev_f32(grad_output[0], "d_logit")
+                                              : torch::zeros({n}, opt);
+    Tensor d_rgb = grad_output[1].defined() ? f2n::dev_f32(grad_output[1], "d_rgb")
+                                            : torch::zeros({n, 3}, opt);
+    Tensor d_enc_cm = torch::empty({(int64_t)C, n}, opt);
+    Tensor g_w_h = torch::zeros_like(w_h), g_b_h = torch::zeros_like(b_h),
+           g_w1 = torch::zeros_like(w1), g_b1 = torch::zeros_like(b1),
+           g_w2 = torch::zeros_like(w2), g_b2 = torch::zeros_like(b2);
+    const bool use_emb = emb.defined() && sample_img.defined();
+    Tensor g_emb = use_emb ? torch::zeros_like(emb) : Tensor();  // undefined = no gradient
+    f2n::check(
+      f2n_shade_bwd(
+        enc_cm.data_ptr<float>(), C, dirs.data_ptr<float>(), use_emb ? f2n::iptr(sample_img) : nullptr,
+        f2n::fptr(w_h), f2n::fptr(b_h), f2n::fptr(w1), f2n::fptr(b1), f2n::fptr(w2), f2n::fptr(b2),
+        f2n::fptr(emb), f2n::fptr(d_logit), f2n::fptr(d_rgb), d_enc_cm.data_ptr<float>(),
+        g_w_h.data_ptr<float>(), g_b_h.data_ptr<float>(), g_w1.data_ptr<float>(),
+        g_b1.data_ptr<float>(), g_w2.data_ptr<float>(), g_b2.data_ptr<float>(),
+        use_emb ? g_emb.data_ptr<float>() : nullptr, n, f2n::current_stream(enc_cm)),
+      "f2n_shade_bwd");
+    // d_enc goes back as an [n, C] view of channel-major storage: f2n_hash_bwd reads it in place
+    return {d_enc_cm.t(), Tensor(), Tensor(), g_w_h, g_b_h, g_w1, g_b1, g_w2, g_b2, g_emb};
+  }
+};
+
 }  // namespace
 
 namespace torch::autograd
@@ -278,6 +356,19 @@ Tensor CustomOps::ScatterIdx(int n_all_pts, Tensor idx_start_end, Tensor emb_idx
       (int)idx_start_end.size(0), f2n::current_stream(idx_start_end)),
     "f2n_scatter_idx");
   return ret;
+}
+
+f2n::ShadeOut f2n::shade(
+  const Tensor & enc, const Tensor & dirs, const Tensor & sample_img, const Tensor & w_h,
+  const Tensor & b_h, const Tensor & w1, const Tensor & b1, const Tensor & w2, const Tensor & b2,
+  const Tensor & app_emb)
+{
+  const Tensor no_img = torch::empty({0}, f2n::int_on(enc.device()));
+  const Tensor no_emb = torch::empty({0, 16}, enc.options());
+  const bool use_emb = sample_img.defined() && app_emb.defined();
+  auto out = ShadeFn::apply(
+    enc, dirs, use_emb ? sample_img : no_img, w_h, b_h, w1, b1, w2, b2, use_emb ? app_emb : no_emb);
+  return {out[0], out[1]};
 }
 
 f2n::CompositeOut f2n::composite(

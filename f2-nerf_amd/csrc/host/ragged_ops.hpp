@@ -51,4 +51,25 @@ CompositeOut composite(
   const Tensor & field_out, const Tensor & rgb, const Tensor & dt, const Tensor & t,
   const Tensor & idx_start_end, const Tensor & bg_color);
 
+
+struct ShadeOut
+{
+  Tensor logit;  // [n]    density logit = row 0 of the field head
+  Tensor rgb;    // [n, 3]
+};
+
+// The per-sample network between hash encode and compositing as one kernel per direction
+// (f2n_shade_fwd / f2n_shade_bwd): field head Linear(C->16), shading-feature assembly with the
+// per-image appearance embedding, SH(dirs), colour MLP 32-64-3 and the scaled sigmoid
+// (reference src/hash_3d_anchored.cpp:86, src/renderer.cpp:93-106, src/sh_shader.cpp:22-29).
+// `enc` is the [n, C] hash encoding (channel-major storage is consumed in place); `sample_img`
+// [n] int32 or undefined (no embedding).  Differentiable in enc and all seven parameter tensors.
+ShadeOut shade(
+  const Tensor & enc, const Tensor & dirs, const Tensor & sample_img, const Tensor & w_h,
+  const Tensor & b_h, const Tensor & w1, const Tensor & b1, const Tensor & w2, const Tensor & b2,
+  const Tensor & app_emb);
+
+// C = L*F values the fused kernel is built for
+inline bool shade_supported(int64_t C) { return C == 8 || C == 16 || C == 32 || C == 64; }
+
 }  // namespace f2n

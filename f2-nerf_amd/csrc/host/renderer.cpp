@@ -120,6 +120,21 @@ RenderResult Renderer::shade_and_composite(
   const SampleResultFlex & kept, const Tensor & emb_idx, RunningMode mode, const Tensor & bg_color)
 {
   const int64_t n_kept = kept.pts.size(0);
+  const int64_t C = scene_field_->options_.n_levels * scene_field_->options_.n_channels;
+  if (options_.fused_shade && f2n::shade_supported(C) && scene_field_->options_.mlp_out_dim == 16) {
+    // hash encode -> one kernel for field head + embedding + SH + colour MLP -> composite
+    Tensor enc = scene_field_->encode(kept.pts);
+    Tensor sample_img;
+    if (mode == RunningMode::TRAIN)
+      sample_img = CustomOps::ScatterIdx((int)n_kept, kept.pts_idx_bounds, emb_idx);
+    auto mlp = shader_->mlp_params();
+    f2n::ShadeOut sh = f2n::shade(
+      enc, kept.dirs, sample_img, scene_field_->mlp_->weight, scene_field_->mlp_->bias, mlp[0],
+      mlp[1], mlp[2], mlp[3], mode == RunningMode::TRAIN ? app_emb_ : Tensor());
+    f2n::CompositeOut out = f2n::composite(
+      sh.logit.unsqueeze(1), sh.rgb, kept.dt, kept.t, kept.pts_idx_bounds, bg_color);
+    return {out.colors, out.depths, out.weights, kept.pts_idx_bounds};
+  }
   Tensor scene_feat = scene_field_->query(kept.pts);  // [n, 16]: col 0 density logit, 1.. shading
 
   Tensor shading_feat = torch::cat(

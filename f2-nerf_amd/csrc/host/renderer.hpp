@@ -36,6 +36,7 @@ struct RendererOptions
   Hash3DAnchoredOptions field;
   PtsSamplerOptions sampler;
   bool fused = true;
+  bool fused_shade = true;         // per-sample network as one kernel (needs L*F in {8,16,32,64})
   float early_stop_trans = 1e-4f;  // renderer.cpp:68
   bool check_finite = false;       // the reference's CHECK(isfinite(colors.mean())) host sync
 };

@@ -32,6 +32,13 @@ Tensor SHShader::query(const Tensor & feats, const Tensor & dirs)
   return (1.f + 2.f * eps) / (1.f + torch::exp(-output)) - eps;
 }
 
+std::vector<Tensor> SHShader::mlp_params() const
+{
+  auto l1 = mlp_->ptr<torch::nn::LinearImpl>(0);
+  auto l2 = mlp_->ptr<torch::nn::LinearImpl>(2);
+  return {l1->weight, l1->bias, l2->weight, l2->bias};
+}
+
 std::vector<torch::optim::OptimizerParamGroup> SHShader::optim_param_groups(float lr)
 {
   auto opt = std::make_unique<torch::optim::AdamOptions>(lr);

@@ -20,6 +20,9 @@ public:
 
   static constexpr int DEGREE = 4;
 
+  // {w1 [64,32], b1 [64], w2 [3,64], b2 [3]} of mlp_, for the Renderer's fused per-sample kernel
+  std::vector<Tensor> mlp_params() const;
+
 private:
   torch::nn::Sequential mlp_ = nullptr;
 };

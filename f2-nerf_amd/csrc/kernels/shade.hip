@@ -1,0 +1,422 @@
+// shade.hip -- the per-sample network between the hash encode and the compositing, fused:
+//   h      = Linear(C -> 16)(enc)                          (Hash3DAnchored::mlp_, reference
+//                                                           src/hash_3d_anchored.cpp:86)
+//   logit  = h[0]                                          (density logit, src/renderer.cpp:93)
+//   X      = [1, h[1..15]] (+ app_emb[image]) ++ SH16(dir) (src/renderer.cpp:95-104,
+//                                                           src/sh_shader.cpp:24-25)
+//   rgb    = (1+2e) * sigmoid(Linear(64->3)(relu(Linear(32->64)(X)))) - e   (src/sh_shader.cpp:26-28)
+// forward and backward, including every parameter gradient.
+//
+// Why: at 8.4 M samples per chunk the three skinny GEMMs (and their transposed/weight-gradient
+// forms) run at ~1 TFLOP/s in rocBLAS and, with the cat / ScatterAdd / bias-reduce kernels around
+// them, cost more than all hash kernels together (profiles/r01_*_kernel_stats.csv).  The layers
+// are 16/64/3 wide, so one lane can carry one sample through the whole network in registers:
+// weights are wave-uniform and stream through SGPRs (scalar loads), activations never touch memory.
+//
+// Backward = recompute forward per sample, propagate, and reduce the weight gradients inside the
+// wavefront without atomics: sample-major vectors are transposed through LDS so that lane j owns
+// row j of the weight gradient and accumulates it in registers over every stride the wave processes;
+// one atomic flush per wave at the end.
+//
+// Activations enc / d_enc are channel-major [C, n] (the layout f2n_hash_fwd / f2n_hash_bwd use).
+#include "sh_basis.hiph"
+
+namespace
+{
+
+constexpr int kOut1 = 16;   // field head width
+constexpr int kIn2 = 32;    // shader input = 16 shading features + 16 SH
+constexpr int kHid = 64;    // shader hidden width
+constexpr float kEps = 1e-3f;
+
+struct ShadeParams
+{
+  const float * __restrict__ w_h;  // [16, C]
+  const float * __restrict__ b_h;  // [16]
+  const float * __restrict__ w1;   // [64, 32]
+  const float * __restrict__ b1;   // [64]
+  const float * __restrict__ w2;   // [3, 64]
+  const float * __restrict__ b2;   // [3]
+  const float * __restrict__ emb;  // [E, 16] or null
+};
+
+// One sample through the network.  All indices are compile-time constants after unrolling, so the
+// arrays live in VGPRs and the weights are fetched with scalar loads.
+template <int C>
+__device__ __forceinline__ void shade_forward(
+  const float (&e)[C], float dx, float dy, float dz, const float * __restrict__ emb_row,
+  const ShadeParams & P, float (&h)[kOut1], float (&X)[kIn2], float (&pre)[kHid], float (&o)[3])
+{
+#pragma unroll
+  for (int i = 0; i < kOut1; i++) {
+    float acc = P.b_h[i];
+#pragma unroll
+    for (int c = 0; c < C; c++) acc = fmaf(e[c], P.w_h[i * C + c], acc);
+    h[i] = acc;
+  }
+  X[0] = 1.f;
+#pragma unroll
+  for (int i = 1; i < kOut1; i++) X[i] = h[i];
+  if (emb_row) {
+#pragma unroll
+    for (int i = 0; i < kOut1; i++) X[i] += emb_row[i];
+  }
+  sh_basis<4>(dx, dy, dz, &X[kOut1]);
+#pragma unroll
+  for (int j = 0; j < kHid; j++) {
+    float acc = P.b1[j];
+#pragma unroll
+    for (int i = 0; i < kIn2; i++) acc = fmaf(X[i], P.w1[j * kIn2 + i], acc);
+    pre[j] = acc;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float acc = P.b2[c];
+#pragma unroll
+    for (int j = 0; j < kHid; j++) acc = fmaf(fmaxf(pre[j], 0.f), P.w2[c * kHid + j], acc);
+    o[c] = acc;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(F2N_BLOCK) void shade_fwd_kernel(
+  const float * __restrict__ enc, const float * __restrict__ dirs,
+  const int32_t * __restrict__ sample_img, const float * __restrict__ p_w_h,
+  const float * __restrict__ p_b_h, const float * __restrict__ p_w1,
+  const float * __restrict__ p_b1, const float * __restrict__ p_w2,
+  const float * __restrict__ p_b2, const float * __restrict__ p_emb, float * __restrict__ logit,
+  float * __restrict__ rgb, int64_t n)
+{
+  const int64_t p = (int64_t)blockIdx.x * F2N_BLOCK + threadIdx.x;
+  if (p >= n) return;
+  const ShadeParams P{p_w_h, p_b_h, p_w1, p_b1, p_w2, p_b2, p_emb};
+  float e[C];
+#pragma unroll
+  for (int c = 0; c < C; c++) e[c] = enc[(int64_t)c * n + p];
+  const float * emb_row = (P.emb && sample_img) ? P.emb + (int64_t)sample_img[p] * kOut1 : nullptr;
+  float h[kOut1], X[kIn2], pre[kHid], o[3];
+  shade_forward<C>(e, dirs[3 * p], dirs[3 * p + 1], dirs[3 * p + 2], emb_row, P, h, X, pre, o);
+  logit[p] = h[0];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+    rgb[3 * p + c] = (1.f + 2.f * kEps) / (1.f + expf(-o[c])) - kEps;
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+
+constexpr int kBwdWaves = 4;             // waves per workgroup
+constexpr int kStrideA = kHid + 4;       // padded row of the [64 samples][64] LDS tile (floats)
+constexpr int kStrideB = kIn2 + 4;       // padded row of the [64 samples][32] LDS tile
+constexpr int kTileA = 64 * kStrideA;    // 17 KiB
+constexpr int kTileB = 64 * kStrideB;    //  9 KiB
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+  // one wavefront's LDS operations execute in order; this only stops the compiler from moving the
+  // transposed reads above the writes of other lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ ShadeParams opaque_params(
+  const float * w_h, const float * b_h, const float * w1, const float * b1, const float * w2,
+  const float * b2, const float * emb)
+{
+  int z;
+  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+  return ShadeParams{w_h + z, b_h + z, w1 + z, b1 + z, w2 + z, b2 + z, emb};
+}
+
+template <int C>
+__global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
+  const float * __restrict__ enc, const float * __restrict__ dirs,
+  const int32_t * __restrict__ sample_img, const float * __restrict__ p_w_h,
+  const float * __restrict__ p_b_h, const float * __restrict__ p_w1,
+  const float * __restrict__ p_b1, const float * __restrict__ p_w2,
+  const float * __restrict__ p_b2, const float * __restrict__ p_emb,
+  const float * __restrict__ d_logit, const float * __restrict__ d_rgb, float * __restrict__ d_enc, float * __restrict__ g_w_h,
+  float * __restrict__ g_b_h, float * __restrict__ g_w1, float * __restrict__ g_b1,
+  float * __restrict__ g_w2, float * __restrict__ g_b2, float * __restrict__ g_emb, int64_t n)
+{
+  static_assert(C % 4 == 0 && C <= kHid, "C must be a multiple of 4 and at most 64");
+  __shared__ __attribute__((aligned(16))) float lds[kBwdWaves * (kTileA + kTileB)];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  float * tileA = lds + wave * (kTileA + kTileB);
+  float * tileB = tileA + kTileA;
+  // The weights must reach the FMAs through scalar loads (SGPR operands).  hipcc only emits s_load
+  // for memory it can prove nothing in the kernel writes: plain `const __restrict__` kernel
+  // arguments qualify, pointers inside a by-value struct do not (the loads then become per-lane
+  // vector loads, 2.8 K live VGPRs, 13 KB/lane of scratch).
+  const bool has_emb = (p_emb != nullptr) && (sample_img != nullptr);
+
+  // per-lane accumulators that live across all strides of this wave
+  float acc_w1[kIn2];  // lane j: d w1[j][:]
+  float acc_b1 = 0.f;  // lane j: d b1[j]
+  float acc_w2[3];     // lane j: d w2[:][j]
+  constexpr int CQ = C / 4;
+  float acc_wh[CQ];    // lane (i = lane&15, q = lane>>4): d w_h[i][q*CQ .. q*CQ+CQ)
+  float acc_bh[kOut1]; // lane = sample partial sums, wave-reduced at the end
+  float acc_b2[3];
+#pragma unroll
+  for (int i = 0; i < kIn2; i++) acc_w1[i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; c++) acc_w2[c] = acc_b2[c] = 0.f;
+#pragma unroll
+  for (int k = 0; k < CQ; k++) acc_wh[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < kOut1; i++) acc_bh[i] = 0.f;
+
+  const int64_t n_strides = (n + 63) / 64;
+  const int64_t wave_global = (int64_t)blockIdx.x * kBwdWaves + wave;
+  const int64_t wave_count = (int64_t)gridDim.x * kBwdWaves;
+  for (int64_t st = wave_global; st < n_strides; st += wave_count) {
+    // The weight addresses are loop-invariant; left alone, LICM hoists all 2.8 K scalar loads out
+    // of this loop and the SGPRs spill through v_writelane/v_readlane (11 K extra instructions).
+    // An opaque zero offset, re-made per stride, keeps every load inside the iteration.
+    ShadeParams P = opaque_params(p_w_h, p_b_h, p_w1, p_b1, p_w2, p_b2, p_emb);
+    const int64_t p = st * 64 + lane;
+    const bool valid = p < n;
+    const int64_t pc = valid ? p : n - 1;  // clamped: tail lanes recompute a real sample, weight 0
+
+    // ---- phase 0: lane = sample; recompute forward, back-propagate to d_enc
+    float e[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) e[c] = enc[(int64_t)c * n + pc];
+    const int img = has_emb ? sample_img[pc] : 0;
+    const float * emb_row = has_emb ? P.emb + (int64_t)img * kOut1 : nullptr;
+    float h[kOut1], X[kIn2], pre[kHid], o[3];
+    shade_forward<C>(e, dirs[3 * pc], dirs[3 * pc + 1], dirs[3 * pc + 2], emb_row, P, h, X, pre, o);
+    // fresh scalar loads for the backward sweep instead of weights kept alive since the forward
+    P = opaque_params(p_w_h, p_b_h, p_w1, p_b1, p_w2, p_b2, p_emb);
+
+    float d_o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float s = 1.f / (1.f + expf(-o[c]));
+      const float g = valid ? d_rgb[3 * pc + c] : 0.f;
+      d_o[c] = g * (1.f + 2.f * kEps) * s * (1.f - s);
+      acc_b2[c] += d_o[c];
+    }
+    // weight rows are walked contiguously (c / j / i outer, row elements inner) so that the scalar
+    // loads stay s_load_dwordx16
+    float d_hid[kHid];
+#pragma unroll
+    for (int j = 0; j < kHid; j++) d_hid[j] = d_o[0] * P.w2[j];
+#pragma unroll
+    for (int c = 1; c < 3; c++) {
+#pragma unroll
+      for (int j = 0; j < kHid; j++) d_hid[j] = fmaf(d_o[c], P.w2[c * kHid + j], d_hid[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kHid; j++) d_hid[j] = (pre[j] > 0.f) ? d_hid[j] : 0.f;
+    float d_h[kOut1];  // d_h[i] for i >= 1 equals dX[i]; dX[0] only feeds the embedding
+    float dX0;
+    {
+      float dX[kOut1];
+#pragma unroll
+      for (int i = 0; i < kOut1; i++) dX[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < kHid; j++) {
+#pragma unroll
+        for (int i = 0; i < kOut1; i++) dX[i] = fmaf(d_hid[j], P.w1[j * kIn2 + i], dX[i]);
+      }
+      dX0 = dX[0];
+      d_h[0] = valid ? d_logit[pc] : 0.f;
+#pragma unroll
+      for (int i = 1; i < kOut1; i++) d_h[i] = dX[i];
+    }
+#pragma unroll
+    for (int i = 0; i < kOut1; i++) acc_bh[i] += d_h[i];
+    {
+      float d_e[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) d_e[c] = d_h[0] * P.w_h[c];
+#pragma unroll
+      for (int i = 1; i < kOut1; i++) {
+#pragma unroll
+        for (int c = 0; c < C; c++) d_e[c] = fmaf(d_h[i], P.w_h[i * C + c], d_e[c]);
+      }
+      if (valid) {
+#pragma unroll
+        for (int c = 0; c < C; c++) d_enc[(int64_t)c * n + p] = d_e[c];
+      }
+    }
+
+    // ---- phase A: d w1[j][i] += sum_s d_hid[s][j] * X[s][i] ; d b1[j] += sum_s d_hid[s][j]
+#pragma unroll
+    for (int j = 0; j < kHid; j += 4)
+      *reinterpret_cast<float4 *>(tileA + lane * kStrideA + j) =
+        make_float4(d_hid[j], d_hid[j + 1], d_hid[j + 2], d_hid[j + 3]);
+#pragma unroll
+    for (int i = 0; i < kIn2; i += 4)
+      *reinterpret_cast<float4 *>(tileB + lane * kStrideB + i) =
+        make_float4(X[i], X[i + 1], X[i + 2], X[i + 3]);
+    wave_lds_sync();
+#pragma unroll 4
+    for (int s = 0; s < 64; s++) {
+      const float a = tileA[s * kStrideA + lane];
+      acc_b1 += a;
+#pragma unroll
+      for (int i = 0; i < kIn2; i += 4) {
+        const float4 x = *reinterpret_cast<const float4 *>(tileB + s * kStrideB + i);
+        acc_w1[i] = fmaf(a, x.x, acc_w1[i]);
+        acc_w1[i + 1] = fmaf(a, x.y, acc_w1[i + 1]);
+        acc_w1[i + 2] = fmaf(a, x.z, acc_w1[i + 2]);
+        acc_w1[i + 3] = fmaf(a, x.w, acc_w1[i + 3]);
+      }
+    }
+    wave_lds_sync();
+
+    // ---- phase B: d w2[c][j] += sum_s d_o[s][c] * relu(pre[s][j])
+#pragma unroll
+    for (int j = 0; j < kHid; j += 4)
+      *reinterpret_cast<float4 *>(tileA + lane * kStrideA + j) = make_float4(
+        fmaxf(pre[j], 0.f), fmaxf(pre[j + 1], 0.f), fmaxf(pre[j + 2], 0.f), fmaxf(pre[j + 3], 0.f));
+    *reinterpret_cast<float4 *>(tileB + lane * 4) = make_float4(d_o[0], d_o[1], d_o[2], 0.f);
+    wave_lds_sync();
+#pragma unroll 8
+    for (int s = 0; s < 64; s++) {
+      const float a = tileA[s * kStrideA + lane];
+      const float4 g = *reinterpret_cast<const float4 *>(tileB + s * 4);
+      acc_w2[0] = fmaf(g.x, a, acc_w2[0]);
+      acc_w2[1] = fmaf(g.y, a, acc_w2[1]);
+      acc_w2[2] = fmaf(g.z, a, acc_w2[2]);
+    }
+    wave_lds_sync();
+
+    // ---- phase C: d w_h[i][c] += sum_s d_h[s][i] * enc[s][c]
+    {
+      constexpr int kStrideE = C + 4;
+      constexpr int kStrideH = kOut1 + 4;
+#pragma unroll
+      for (int c = 0; c < C; c += 4)
+        *reinterpret_cast<float4 *>(tileA + lane * kStrideE + c) =
+          make_float4(e[c], e[c + 1], e[c + 2], e[c + 3]);
+#pragma unroll
+      for (int i = 0; i < kOut1; i += 4)
+        *reinterpret_cast<float4 *>(tileB + lane * kStrideH + i) =
+          make_float4(d_h[i], d_h[i + 1], d_h[i + 2], d_h[i + 3]);
+      wave_lds_sync();
+      const int wi = lane & 15, wq = lane >> 4;
+#pragma unroll 4
+      for (int s = 0; s < 64; s++) {
+        const float a = tileB[s * kStrideH + wi];
+#pragma unroll
+        for (int k = 0; k < CQ; k += 4) {
+          const float4 x = *reinterpret_cast<const float4 *>(tileA + s * kStrideE + wq * CQ + k);
+          acc_wh[k] = fmaf(a, x.x, acc_wh[k]);
+          if (k + 1 < CQ) acc_wh[k + 1] = fmaf(a, x.y, acc_wh[k + 1]);
+          if (k + 2 < CQ) acc_wh[k + 2] = fmaf(a, x.z, acc_wh[k + 2]);
+          if (k + 3 < CQ) acc_wh[k + 3] = fmaf(a, x.w, acc_wh[k + 3]);
+        }
+      }
+      wave_lds_sync();
+    }
+
+    // ---- phase D: appearance embedding, d emb[img][i] += dX[i] (i = 0 included: X[0] = 1 + emb[0])
+    if (has_emb) {
+      const int img0 = __builtin_amdgcn_readfirstlane(img);
+      const bool uniform = __all(img == img0);
+      if (uniform) {
+        constexpr int kStrideH = kOut1 + 4;
+        *reinterpret_cast<float4 *>(tileB + lane * kStrideH) =
+          make_float4(valid ? dX0 : 0.f, d_h[1], d_h[2], d_h[3]);
+#pragma unroll
+        for (int i = 4; i < kOut1; i += 4)
+          *reinterpret_cast<float4 *>(tileB + lane * kStrideH + i) =
+            make_float4(d_h[i], d_h[i + 1], d_h[i + 2], d_h[i + 3]);
+        wave_lds_sync();
+        // lane (i = lane&15, part = lane>>4) sums 16 of the 64 samples, then the 4 parts combine
+        float part = 0.f;
+        const int ei = lane & 15, eq = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < 16; s++) part += tileB[(eq * 16 + s) * kStrideH + ei];
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (lane < 16) atomicAdd(g_emb + (int64_t)img0 * kOut1 + lane, part);
+        wave_lds_sync();
+      } else if (valid) {
+        atomicAdd(g_emb + (int64_t)img * kOut1, dX0);
+#pragma unroll
+        for (int i = 1; i < kOut1; i++) atomicAdd(g_emb + (int64_t)img * kOut1 + i, d_h[i]);
+      }
+    }
+  }
+
+  // ---- flush this wave's accumulators
+#pragma unroll
+  for (int i = 0; i < kIn2; i++) atomicAdd(g_w1 + lane * kIn2 + i, acc_w1[i]);
+  atomicAdd(g_b1 + lane, acc_b1);
+#pragma unroll
+  for (int c = 0; c < 3; c++) atomicAdd(g_w2 + c * kHid + lane, acc_w2[c]);
+  {
+    const int wi = lane & 15, wq = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < CQ; k++) atomicAdd(g_w_h + wi * C + wq * CQ + k, acc_wh[k]);
+  }
+#pragma unroll
+  for (int i = 0; i < kOut1; i++) {
+    const float t = wave_sum(acc_bh[i]);
+    if (lane == 0) atomicAdd(g_b_h + i, t);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const float t = wave_sum(acc_b2[c]);
+    if (lane == 0) atomicAdd(g_b2 + c, t);
+  }
+}
+
+}  // namespace
+
+#define F2N_DISPATCH_C(C_, ...)                                   \
+  switch (C_) {                                                   \
+    case 8: { constexpr int CC = 8; __VA_ARGS__; } break;         \
+    case 16: { constexpr int CC = 16; __VA_ARGS__; } break;       \
+    case 32: { constexpr int CC = 32; __VA_ARGS__; } break;       \
+    case 64: { constexpr int CC = 64; __VA_ARGS__; } break;       \
+    default: return F2N_E_UNSUPPORTED;                            \
+  }
+
+extern "C" int f2n_shade_fwd(
+  const float * enc_cm, int C, const float * dirs, const int32_t * sample_img, const float * w_h,
+  const float * b_h, const float * w1, const float * b1, const float * w2, const float * b2,
+  const float * app_emb, float * logit, float * rgb, int64_t n, void * stream)
+{
+  if (n < 0) return F2N_E_INVALID_ARG;
+  if (C != 8 && C != 16 && C != 32 && C != 64) return F2N_E_UNSUPPORTED;
+  if (n == 0) return F2N_OK;
+  if (!enc_cm || !dirs || !w_h || !b_h || !w1 || !b1 || !w2 || !b2 || !logit || !rgb)
+    return F2N_E_INVALID_ARG;
+  const dim3 grid(f2n_div_up(n, F2N_BLOCK)), block(F2N_BLOCK);
+  F2N_DISPATCH_C(C, hipLaunchKernelGGL(
+                      (shade_fwd_kernel<CC>), grid, block, 0, (hipStream_t)stream, enc_cm, dirs,
+                      sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, logit, rgb, n))
+  return f2n_launch_status();
+}
+
+extern "C" int f2n_shade_bwd(
+  const float * enc_cm, int C, const float * dirs, const int32_t * sample_img, const float * w_h,
+  const float * b_h, const float * w1, const float * b1, const float * w2, const float * b2,
+  const float * app_emb, const float * d_logit, const float * d_rgb, float * d_enc_cm,
+  float * g_w_h, float * g_b_h, float * g_w1, float * g_b1, float * g_w2, float * g_b2,
+  float * g_app_emb, int64_t n, void * stream)
+{
+  if (n < 0) return F2N_E_INVALID_ARG;
+  if (C != 8 && C != 16 && C != 32 && C != 64) return F2N_E_UNSUPPORTED;
+  if (n == 0) return F2N_OK;
+  if (!enc_cm || !dirs || !w_h || !b_h || !w1 || !b1 || !w2 || !b2 || !d_logit || !d_rgb ||
+      !d_enc_cm || !g_w_h || !g_b_h || !g_w1 || !g_b1 || !g_w2 || !g_b2)
+    return F2N_E_INVALID_ARG;
+  if (app_emb && sample_img && !g_app_emb) return F2N_E_INVALID_ARG;
+  const int64_t n_strides = (n + 63) / 64;
+  // persistent waves: one workgroup per CU is all the LDS allows (4 x 26 KiB); fewer if n is small
+  const unsigned grid = (unsigned)std::min<int64_t>(256, (n_strides + kBwdWaves - 1) / kBwdWaves);
+  F2N_DISPATCH_C(C, hipLaunchKernelGGL(
+                      (shade_bwd_kernel<CC>), dim3(grid), dim3(kBwdWaves * 64), 0,
+                      (hipStream_t)stream, enc_cm, dirs, sample_img, w_h, b_h, w1, b1, w2, b2,
+                      app_emb, d_logit, d_rgb, d_enc_cm,
+                      g_w_h, g_b_h, g_w1, g_b1, g_w2, g_b2, g_app_emb, n))
+  return f2n_launch_status();
+}

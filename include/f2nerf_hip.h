@@ -177,6 +177,34 @@ int f2n_composite_bwd(
   const float * d_colors, const float * d_depths, const float * d_weights, float * d_logit,
   float * d_rgb, int n_rays, float density_shift, float t_shift, void * stream);
 
+/* ------------------------------------------------------------------ fused per-sample network -- */
+
+/* Everything between the hash encode and the compositing, one kernel per direction:
+ *   h = mlp(enc)                       Linear(C->16) of Hash3DAnchored::query -- src/hash_3d_anchored.cpp:86
+ *   logit = h[0]                       density logit                          -- src/renderer.cpp:93
+ *   X = cat(1, h[1:16]) (+ app_emb[sample_img]) ++ SH16(dirs)                 -- src/renderer.cpp:95-104,
+ *                                                                                src/sh_shader.cpp:24-25
+ *   rgb = (1+2e)*sigmoid(mlp2(relu(mlp1(X)))) - e, e = 1e-3                   -- src/sh_shader.cpp:26-28
+ * i.e. the three nn::Linear GEMMs, torch::cat x2, ScatterAdd (src/CustomOps/Scatter.cu:11-19),
+ * SHKernel (src/sh_shader.cu:11-103) and the element-wise tail.  enc_cm / d_enc_cm are
+ * channel-major [C, n] (C = L*F in {8,16,32,64}); w_h [16,C], w1 [64,32], w2 [3,64] row-major as
+ * nn::Linear stores them; sample_img [n] image id per sample or NULL (no appearance embedding). */
+int f2n_shade_fwd(
+  const float * enc_cm, int C, const float * dirs, const int32_t * sample_img, const float * w_h,
+  const float * b_h, const float * w1, const float * b1, const float * w2, const float * b2,
+  const float * app_emb, float * logit, float * rgb, int64_t n, void * stream);
+
+/* Backward of the above (recomputes the forward per sample).  d_enc_cm is overwritten; the seven
+ * parameter gradients are ACCUMULATED INTO (caller zeroes them); g_app_emb may be NULL when
+ * app_emb / sample_img are.  Replaces the autograd chain of the ops listed above, including
+ * ScatterAddFuncBackwardBlock -- src/CustomOps/Scatter.cu:21-41,72-101. */
+int f2n_shade_bwd(
+  const float * enc_cm, int C, const float * dirs, const int32_t * sample_img, const float * w_h,
+  const float * b_h, const float * w1, const float * b1, const float * w2, const float * b2,
+  const float * app_emb, const float * d_logit, const float * d_rgb, float * d_enc_cm,
+  float * g_w_h, float * g_b_h, float * g_w1, float * g_b1, float * g_w2, float * g_b2,
+  float * g_app_emb, int64_t n, void * stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,8 +74,9 @@ def test_render_against_golden(dev):
         for k, v in ren.named_parameters().items():
             v.copy_(z["param." + k].to(dev))
     to = lambda k: z[k].to(dev)
-    for fused in (True, False):
+    for fused, fused_shade in ((True, True), (True, False), (False, False)):
         ren.set_fused(fused)
+        ren.set_fused_shade(fused_shade)
         ren.zero_grad()
         c, d, w, idx = ren.render(to("rays_o"), to("rays_d"), to("emb_idx"), "train", to("noise"),
                                   to("bg"))

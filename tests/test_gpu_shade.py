@@ -1,0 +1,74 @@
+"""Fused per-sample network kernels (f2n_shade_fwd / f2n_shade_bwd) against the op-by-op torch-CPU
+composition of the same reference lines (hash_3d_anchored.cpp:86, renderer.cpp:93-104,
+sh_shader.cpp:22-29) with torch autograd for every gradient."""
+import pytest
+import torch
+
+from oracle import kernels as K
+
+pytestmark = pytest.mark.gpu
+EPS = 1e-3
+
+
+def _reference(enc, dirs, img, P, d_logit, d_rgb):
+    enc = enc.clone().requires_grad_(True)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    h = enc @ P["w_h"].t() + P["b_h"]
+    logit = h[:, 0]
+    X = torch.cat([torch.ones_like(h[:, :1]), h[:, 1:]], 1)
+    if img is not None:
+        X = X + P["emb"][img.long()]
+    X = torch.cat([X, K.sh_encode(dirs, 4)], 1)
+    hid = torch.relu(X @ P["w1"].t() + P["b1"])
+    o = hid @ P["w2"].t() + P["b2"]
+    rgb = (1 + 2 * EPS) / (1 + torch.exp(-o)) - EPS
+    ((logit * d_logit).sum() + (rgb * d_rgb).sum()).backward()
+    return logit.detach(), rgb.detach(), enc.grad, {k: v.grad for k, v in P.items()}
+
+
+@pytest.mark.parametrize("C,n,with_emb", [(32, 5000, True), (32, 64 * 9 + 17, False), (8, 3000, True),
+                                          (64, 2000, True), (16, 1, True)])
+def test_shade_fwd_bwd(capi, dev, C, n, with_emb):
+    g = torch.Generator().manual_seed(C + n)
+    E = 5
+    enc = (torch.randn(n, C, generator=g) * 0.1).to(torch.float16).float()
+    dirs = torch.randn(n, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    # image ids: runs of equal ids (samples of one ray) with a few changes inside a 64-sample stride
+    img = (torch.arange(n) // 37 % E).to(torch.int32) if with_emb else None
+    P = {"w_h": torch.randn(16, C, generator=g) * 0.3, "b_h": torch.randn(16, generator=g) * 0.1,
+         "w1": torch.randn(64, 32, generator=g) * 0.3, "b1": torch.randn(64, generator=g) * 0.1,
+         "w2": torch.randn(3, 64, generator=g) * 0.3, "b2": torch.randn(3, generator=g) * 0.1,
+         "emb": torch.randn(E, 16, generator=g) * 0.1}
+    d_logit = torch.randn(n, generator=g)
+    d_rgb = torch.randn(n, 3, generator=g)
+    r_logit, r_rgb, r_denc, r_g = _reference(enc, dirs, img, P, d_logit, d_rgb)
+
+    dv = lambda t: t.to(dev).contiguous()
+    enc_cm = dv(enc.t())
+    Pd = {k: dv(v) for k, v in P.items()}
+    d_img = dv(img) if with_emb else None
+    emb = Pd["emb"] if with_emb else None
+    logit = torch.empty(n, device=dev)
+    rgb = torch.empty(n, 3, device=dev)
+    capi.call("shade_fwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
+              Pd["w2"], Pd["b2"], emb, logit, rgb, n)
+    torch.testing.assert_close(logit.cpu(), r_logit, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rgb.cpu(), r_rgb, rtol=1e-4, atol=1e-5)
+
+    d_enc = torch.full((C, n), 7.0, device=dev)      # must be overwritten
+    G = {k: torch.zeros_like(v) for k, v in Pd.items()}
+    capi.call("shade_bwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
+              Pd["w2"], Pd["b2"], emb, dv(d_logit), dv(d_rgb), d_enc, G["w_h"], G["b_h"], G["w1"],
+              G["b1"], G["w2"], G["b2"], G["emb"] if with_emb else None, n)
+    torch.testing.assert_close(d_enc.t().cpu(), r_denc, rtol=1e-3, atol=1e-4 * float(r_denc.abs().max()))
+    for k in ("w_h", "b_h", "w1", "b1", "w2", "b2") + (("emb",) if with_emb else ()):
+        ref = r_g[k]
+        torch.testing.assert_close(G[k].cpu(), ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max()),
+                                   msg=lambda m, k=k: k + ": " + m)
+    # accumulate semantics of the parameter gradients
+    capi.call("shade_bwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
+              Pd["w2"], Pd["b2"], emb, dv(d_logit), dv(d_rgb), d_enc, G["w_h"], G["b_h"], G["w1"],
+              G["b1"], G["w2"], G["b2"], G["emb"] if with_emb else None, n)
+    torch.testing.assert_close(G["w1"].cpu(), 2 * r_g["w1"], rtol=1e-3,
+                               atol=4e-4 * float(r_g["w1"].abs().max()))
