@@ -30,7 +30,7 @@ def parse_header(path=HEADER):
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
     decls = {}
-    for m in re.finditer(r"\b(int|const char \*)\s*(f2n_\w+)\s*\(([^)]*)\)\s*;", text):
+    for m in re.finditer(r"\b(int64_t|int|const char \*)\s*(f2n_\w+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         params = []
         args = " ".join(args.split())
@@ -42,7 +42,9 @@ def parse_header(path=HEADER):
                 else:
                     toks = a.replace("const ", "").split()
                     params.append((_CTYPES[toks[0]], toks[-1]))
-        decls[name] = (ctypes.c_char_p if "char" in ret else ctypes.c_int, params)
+        restype = ctypes.c_char_p if "char" in ret else (
+            ctypes.c_int64 if ret == "int64_t" else ctypes.c_int)
+        decls[name] = (restype, params)
     return decls
 
 

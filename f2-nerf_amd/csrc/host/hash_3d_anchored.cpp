@@ -248,16 +248,32 @@ variable_list Hash3DAnchoredFunction::backward(AutogradContext * ctx, variable_l
   const bool want_points = ctx->needs_input_grad(0);
   Tensor points_grad = want_points ? torch::empty({n, 3}, points.options()) : Tensor();
   Tensor embeds_grad = torch::zeros_like(feat_pool);
-  {
-    f2n::ScopedKernelTimer timer("hash_bwd", f2n::current_stream(points), (double)n);
+  void * stream = f2n::current_stream(points);
+  // Large training batches: bin the contributions by table slice into a scratch workspace and
+  // reduce them in LDS (no scattered atomics; exact, order-independent sums).  288 GB of HBM make
+  // the ~2 bytes-per-algorithmic-byte workspace a non-issue; the caching allocator recycles it.
+  const int64_t ws_bytes =
+    want_points ? 0 : f2n_hash_bwd_workspace_bytes(n, L, F, (uint32_t)field->local_size_);
+  if (ws_bytes > 0 && field->options_.binned_backward) {
+    Tensor ws = torch::empty({ws_bytes}, points.options().dtype(torch::kUInt8));
+    f2n::ScopedKernelTimer timer("hash_bwd", stream, (double)n);
+    f2n::check(
+      f2n_hash_bwd_binned(
+        points.data_ptr<float>(), field->prim_pool_.data_ptr<int32_t>(),
+        field->bias_pool_.data_ptr<float>(), field->level_mul_.data_ptr<float>(),
+        grad_in.data_ptr<float>(), ld_point, ld_chan, embeds_grad.data_ptr<float>(), n, L, F,
+        (uint32_t)field->local_size_, field->level_stride_, grad_scale, ws.data_ptr(), ws_bytes,
+        stream),
+      "f2n_hash_bwd_binned");
+  } else {
+    f2n::ScopedKernelTimer timer("hash_bwd", stream, (double)n);
     f2n::check(
       f2n_hash_bwd(
         points.data_ptr<float>(), reinterpret_cast<const uint16_t *>(table16.data_ptr()),
         field->prim_pool_.data_ptr<int32_t>(), field->bias_pool_.data_ptr<float>(),
         field->level_mul_.data_ptr<float>(), grad_in.data_ptr<float>(), ld_point, ld_chan,
         embeds_grad.data_ptr<float>(), want_points ? points_grad.data_ptr<float>() : nullptr, n, L,
-        F, (uint32_t)field->local_size_, field->level_stride_, grad_scale,
-        f2n::current_stream(points)),
+        F, (uint32_t)field->local_size_, field->level_stride_, grad_scale, stream),
       "f2n_hash_bwd");
   }
   return {points_grad, embeds_grad, Tensor()};

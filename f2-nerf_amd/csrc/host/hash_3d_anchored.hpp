@@ -25,6 +25,7 @@ struct Hash3DAnchoredOptions
   int64_t level_stride = 0;  // elements between level bases; 0 = reference behaviour (= rows per
                              // level, so adjacent levels overlap)
   int64_t mlp_out_dim = 16;
+  bool binned_backward = true;  // large batches: f2n_hash_bwd_binned (needs a scratch workspace)
   torch::Device device = f2n::default_device();
 };
 

@@ -70,6 +70,20 @@ int f2n_hash_bwd(
   float * table_grad, float * pts_grad, int64_t n, int L, int F, uint32_t T, int64_t level_stride,
   float grad_scale, void * stream);
 
+/* Same operation as f2n_hash_bwd without the point gradient, for large batches: contributions are
+ * binned by table slice into a caller-provided workspace and reduced in LDS, so the scattered
+ * f16/f32 atomics of Hash3DAnchoredBackwardKernel (src/hash_3d_anchored.cu:129-137) disappear.
+ * f2n_hash_bwd_workspace_bytes returns the recommended workspace size, or 0 when the binned path
+ * does not apply to (n, L, F, T) -- use f2n_hash_bwd then.  workspace: device memory, 256-byte
+ * aligned, contents undefined on entry and exit; a smaller workspace only lowers the capacity
+ * (overflow is applied with direct atomics, results are unaffected). */
+int64_t f2n_hash_bwd_workspace_bytes(int64_t n, int L, int F, uint32_t T);
+int f2n_hash_bwd_binned(
+  const float * pts, const int32_t * primes, const float * bias, const float * mul,
+  const float * grad_out, int64_t g_ld_point, int64_t g_ld_chan, float * table_grad, int64_t n,
+  int L, int F, uint32_t T, int64_t level_stride, float grad_scale, void * workspace,
+  int64_t workspace_bytes, void * stream);
+
 /* Scene contraction of Hash3DAnchored::query -- src/hash_3d_anchored.cpp:79-82 (8 ATen launches):
  *   x = p if |p| <= 1 else (2 - 1/|p|) * p/|p|, evaluated as the reference's mask expression
  *   (|p| == 0 gives NaN, quirk Q6).  The backward is the Jacobian-vector product autograd builds. */

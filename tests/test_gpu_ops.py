@@ -133,6 +133,43 @@ def test_hash_bwd_sliced_path(capi, dev, L, F, T, stride, n):
     assert ((tg.cpu() - ref_tg).norm() / ref_tg.norm()).item() < 1e-6
 
 
+@pytest.mark.parametrize("L,F,log2_T,stride_mode,n,ws_frac", [
+    (16, 2, 19, "ref", 70000, 1.0),     # reference size, recommended workspace
+    (16, 2, 19, "ref", 70000, 0.3),     # small workspace: region overflow -> direct atomics
+    (4, 4, 17, "disjoint", 66000, 1.0),
+    (3, 1, 20, "disjoint", 66000, 1.0),
+])
+def test_hash_bwd_binned_path(capi, dev, L, F, log2_T, stride_mode, n, ws_frac):
+    """Binned backward (bin into workspace + LDS reduce): same contributions as the atomic kernel."""
+    T = 1 << log2_T
+    fld = util.make_field(L, F, log2_T, None if stride_mode == "ref" else T * F, seed=5 + F)
+    st = fld["stride"]
+    pts = util.ball_points(n, seed=21)
+    pts[: n // 2] *= 0.02          # half the points in a tiny ball: coarse levels hit few rows (skew)
+    g = torch.Generator().manual_seed(15)
+    grad = torch.randn(n, L * F, generator=g) * 1e-3
+    grad[torch.rand(n, L * F, generator=g) < 0.1] = 0.0
+    numel = fld["table"].numel()
+    ref_tg, _ = K.hash_bwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad,
+                           numel, L, F, T, st, 128.0, parallel=True)
+    need = capi.lib().cdll.f2n_hash_bwd_workspace_bytes(n, L, F, T)
+    assert need > 0
+    nbytes = int(need * ws_frac) // 256 * 256
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d = _to(dev, pts, fld["primes"], fld["bias"], fld["mul"], grad)
+    tg = torch.zeros(numel, device=dev)
+    capi.call("hash_bwd_binned", *d, L * F, 1, tg, n, L, F, T, st, 128.0, ws, nbytes)
+    scale = ref_tg.abs().max().item()
+    assert (tg.cpu() - ref_tg).abs().max().item() <= 2e-5 * scale
+    assert ((tg.cpu() - ref_tg).norm() / ref_tg.norm()).item() < 1e-5
+    # channel-major gradients give the same result
+    tg2 = torch.zeros(numel, device=dev)
+    capi.call("hash_bwd_binned", d[0], d[1], d[2], d[3], d[4].t().contiguous(), 1, n, tg2, n, L, F,
+              T, st, 128.0, ws, nbytes)
+    assert (tg2.cpu() - ref_tg).abs().max().item() <= 2e-5 * scale
+    assert capi.lib().cdll.f2n_hash_bwd_workspace_bytes(100, L, F, T) == 0   # small n: not applicable
+
+
 def test_table_cast(capi, dev):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1 << 16, generator=g) * 0.1

@@ -93,6 +93,14 @@ def main():
             except Exception as e:
                 print("  bwd %s %s: %s" % (mode, name, e))
     os.environ.pop("F2N_HASH_BWD", None)
+    need = capi.lib().cdll.f2n_hash_bwd_workspace_bytes(n, L, F, T)
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        for name, gr, ldp, ldc in (("row-major", grad_rm, C, 1), ("chan-major", grad_cm, 1, n)):
+            med, best = timeit(lambda: capi.call("hash_bwd_binned", pts, primes, bias, mul, gr, ldp, ldc, tg,
+                                                 n, L, F, T, stride, 128.0, ws, need), max(2, args.reps // 2))
+            print("  bwd binned  grads %-10s %8.3f ms (best %8.3f)  %7.1f GB/s algorithmic  (ws %.1f GiB)" %
+                  (name, med, best, n * bytes_fwd / med / 1e6, need / 2 ** 30))
 
 
 if __name__ == "__main__":
