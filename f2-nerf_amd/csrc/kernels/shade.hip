@@ -16,7 +16,7 @@
 // Backward = recompute forward per sample, propagate, and reduce the weight gradients inside the
 // wavefront without atomics: sample-major vectors are transposed through LDS so that lane j owns
 // row j of the weight gradient and accumulates it in registers over every stride the wave processes;
-// one atomic flush per wave at the end.
+// one atomic flush per wave at the end.  Weights are staged in LDS there (see shade_bwd_kernel).
 //
 // Activations enc / d_enc are channel-major [C, n] (the layout f2n_hash_fwd / f2n_hash_bwd use).
 #include "sh_basis.hiph"
@@ -103,12 +103,27 @@ __global__ __launch_bounds__(F2N_BLOCK) void shade_fwd_kernel(
 }
 
 // ---- backward -----------------------------------------------------------------------------------
+//
+// Structure of one stride (64 samples, lane = sample) -- everything wave-private, no workgroup
+// barriers after the weights are staged:
+//   1. forward recompute with ROLLED loops over the output neuron: the neuron's weight row comes from
+//      LDS (wave-uniform ds_read_b128 = broadcast), the result goes to a [neuron][65] LDS tile (own
+//      column: conflict-free), so no register array is indexed dynamically and the code stays small.
+//      (Fully unrolled variants -- weights through SGPRs or through LDS -- made hipcc hoist hundreds
+//      of weight loads to the top of a 10 K-instruction block and spill 8-13 KB per lane.)
+//   2. d w2 += d_o (x) relu(pre)            lane j owns column j of w2: transposed reads of the tile
+//   3. backward over the hidden layer, rolled over j: d_hid[j] replaces pre[j] in the tile in place,
+//      dX[0:16] accumulates in registers
+//   4. d w1[j][:] += d_hid[s][j] * X[s][:]  lane j owns row j: transposed tile reads + broadcast X
+//   5. d_enc = w_h^T d_h (rolled over the 16 head outputs), d w_h, biases, embedding
+// The [64][65] tile is read conflict-free both ways: element (s, j) sits at j*65 + s.
 
-constexpr int kBwdWaves = 4;             // waves per workgroup
-constexpr int kStrideA = kHid + 4;       // padded row of the [64 samples][64] LDS tile (floats)
-constexpr int kStrideB = kIn2 + 4;       // padded row of the [64 samples][32] LDS tile
-constexpr int kTileA = 64 * kStrideA;    // 17 KiB
-constexpr int kTileB = 64 * kStrideB;    //  9 KiB
+constexpr int kBwdWaves = 4;            // waves per workgroup
+constexpr int kTP = 65;                 // row pitch of the [neuron][sample] tile
+constexpr int kTileP = 64 * (kHid + 4);  // 17 KiB: holds [64][65] and, in step 5b, [64 samples][C+4]
+constexpr int kXP = kIn2 + 4;           // row pitch of the [sample][32] tile (float4 rows)
+constexpr int kTileX = 64 * kXP;        //  9 KiB
+constexpr int kWavelds = kTileP + kTileX;
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -119,15 +134,6 @@ __device__ __forceinline__ void wave_lds_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ ShadeParams opaque_params(
-  const float * w_h, const float * b_h, const float * w1, const float * b1, const float * w2,
-  const float * b2, const float * emb)
-{
-  int z;
-  asm volatile("s_mov_b32 %0, 0" : "=s"(z));
-  return ShadeParams{w_h + z, b_h + z, w1 + z, b1 + z, w2 + z, b2 + z, emb};
-}
-
 template <int C>
 __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
   const float * __restrict__ enc, const float * __restrict__ dirs,
@@ -135,20 +141,36 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
   const float * __restrict__ p_b_h, const float * __restrict__ p_w1,
   const float * __restrict__ p_b1, const float * __restrict__ p_w2,
   const float * __restrict__ p_b2, const float * __restrict__ p_emb,
-  const float * __restrict__ d_logit, const float * __restrict__ d_rgb, float * __restrict__ d_enc, float * __restrict__ g_w_h,
-  float * __restrict__ g_b_h, float * __restrict__ g_w1, float * __restrict__ g_b1,
-  float * __restrict__ g_w2, float * __restrict__ g_b2, float * __restrict__ g_emb, int64_t n)
+  const float * __restrict__ d_logit, const float * __restrict__ d_rgb, float * __restrict__ d_enc,
+  float * __restrict__ g_w_h, float * __restrict__ g_b_h, float * __restrict__ g_w1,
+  float * __restrict__ g_b1, float * __restrict__ g_w2, float * __restrict__ g_b2,
+  float * __restrict__ g_emb, int64_t n)
 {
   static_assert(C % 4 == 0 && C <= kHid, "C must be a multiple of 4 and at most 64");
-  __shared__ __attribute__((aligned(16))) float lds[kBwdWaves * (kTileA + kTileB)];
+  // weights, staged once per workgroup: rows padded by 4 floats with the bias in the first pad slot
+  constexpr int kWhP = C + 4, kW1P = kIn2 + 4;
+  constexpr int kOffWh = 0, kOffW1 = kOffWh + kOut1 * kWhP, kOffW2T = kOffW1 + kHid * kW1P,
+                kOffB2 = kOffW2T + kHid * 4, kWTotal = kOffB2 + 4;
+  __shared__ __attribute__((aligned(16))) float lds_w[kWTotal];
+  __shared__ __attribute__((aligned(16))) float lds[kBwdWaves * kWavelds];
+  for (int i = threadIdx.x; i < kOut1 * C; i += kBwdWaves * 64)
+    lds_w[kOffWh + (i / C) * kWhP + (i % C)] = p_w_h[i];
+  for (int i = threadIdx.x; i < kHid * kIn2; i += kBwdWaves * 64)
+    lds_w[kOffW1 + (i / kIn2) * kW1P + (i % kIn2)] = p_w1[i];
+  for (int i = threadIdx.x; i < 3 * kHid; i += kBwdWaves * 64)
+    lds_w[kOffW2T + (i % kHid) * 4 + (i / kHid)] = p_w2[i];  // transposed: [j][c]
+  if (threadIdx.x < kOut1) lds_w[kOffWh + threadIdx.x * kWhP + C] = p_b_h[threadIdx.x];
+  if (threadIdx.x < kHid) {
+    lds_w[kOffW1 + threadIdx.x * kW1P + kIn2] = p_b1[threadIdx.x];
+    lds_w[kOffW2T + threadIdx.x * 4 + 3] = 0.f;
+  }
+  if (threadIdx.x < 4) lds_w[kOffB2 + threadIdx.x] = (threadIdx.x < 3) ? p_b2[threadIdx.x] : 0.f;
+  __syncthreads();
+
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
-  float * tileA = lds + wave * (kTileA + kTileB);
-  float * tileB = tileA + kTileA;
-  // The weights must reach the FMAs through scalar loads (SGPR operands).  hipcc only emits s_load
-  // for memory it can prove nothing in the kernel writes: plain `const __restrict__` kernel
-  // arguments qualify, pointers inside a by-value struct do not (the loads then become per-lane
-  // vector loads, 2.8 K live VGPRs, 13 KB/lane of scratch).
+  float * tileP = lds + wave * kWavelds;  // [64 neurons][65]: pre-activations, then d_hid
+  float * tileX = tileP + kTileP;         // [64 samples][36] rows, reused for small per-sample vectors
   const bool has_emb = (p_emb != nullptr) && (sample_img != nullptr);
 
   // per-lane accumulators that live across all strides of this wave
@@ -172,95 +194,135 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
   const int64_t wave_global = (int64_t)blockIdx.x * kBwdWaves + wave;
   const int64_t wave_count = (int64_t)gridDim.x * kBwdWaves;
   for (int64_t st = wave_global; st < n_strides; st += wave_count) {
-    // The weight addresses are loop-invariant; left alone, LICM hoists all 2.8 K scalar loads out
-    // of this loop and the SGPRs spill through v_writelane/v_readlane (11 K extra instructions).
-    // An opaque zero offset, re-made per stride, keeps every load inside the iteration.
-    ShadeParams P = opaque_params(p_w_h, p_b_h, p_w1, p_b1, p_w2, p_b2, p_emb);
     const int64_t p = st * 64 + lane;
     const bool valid = p < n;
     const int64_t pc = valid ? p : n - 1;  // clamped: tail lanes recompute a real sample, weight 0
 
-    // ---- phase 0: lane = sample; recompute forward, back-propagate to d_enc
+    // ---- 1. forward recompute
     float e[C];
 #pragma unroll
     for (int c = 0; c < C; c++) e[c] = enc[(int64_t)c * n + pc];
     const int img = has_emb ? sample_img[pc] : 0;
-    const float * emb_row = has_emb ? P.emb + (int64_t)img * kOut1 : nullptr;
-    float h[kOut1], X[kIn2], pre[kHid], o[3];
-    shade_forward<C>(e, dirs[3 * pc], dirs[3 * pc + 1], dirs[3 * pc + 2], emb_row, P, h, X, pre, o);
-    // fresh scalar loads for the backward sweep instead of weights kept alive since the forward
-    P = opaque_params(p_w_h, p_b_h, p_w1, p_b1, p_w2, p_b2, p_emb);
+    float X[kIn2];
+    {
+      // field head: h[i] -> column i of tileX viewed as [16][64]
+#pragma unroll 2
+      for (int i = 0; i < kOut1; i++) {
+        const float * row = lds_w + kOffWh + i * kWhP;
+        float acc = row[C];
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+          const float4 w = *reinterpret_cast<const float4 *>(row + c);
+          acc = fmaf(e[c], w.x, acc);
+          acc = fmaf(e[c + 1], w.y, acc);
+          acc = fmaf(e[c + 2], w.z, acc);
+          acc = fmaf(e[c + 3], w.w, acc);
+        }
+        tileX[i * 64 + lane] = acc;
+      }
+      X[0] = 1.f;
+#pragma unroll
+      for (int i = 1; i < kOut1; i++) X[i] = tileX[i * 64 + lane];
+      if (has_emb) {
+        const float * emb_row = p_emb + (int64_t)img * kOut1;
+#pragma unroll
+        for (int i = 0; i < kOut1; i++) X[i] += emb_row[i];
+      }
+      sh_basis<4>(dirs[3 * pc], dirs[3 * pc + 1], dirs[3 * pc + 2], &X[kOut1]);
+    }
+    float o[3];
+    {
+      const float4 b2 = *reinterpret_cast<const float4 *>(lds_w + kOffB2);
+      o[0] = b2.x;
+      o[1] = b2.y;
+      o[2] = b2.z;
+#pragma unroll 2
+      for (int j = 0; j < kHid; j++) {
+        const float * row = lds_w + kOffW1 + j * kW1P;
+        float acc = row[kIn2];
+#pragma unroll
+        for (int i = 0; i < kIn2; i += 4) {
+          const float4 w = *reinterpret_cast<const float4 *>(row + i);
+          acc = fmaf(X[i], w.x, acc);
+          acc = fmaf(X[i + 1], w.y, acc);
+          acc = fmaf(X[i + 2], w.z, acc);
+          acc = fmaf(X[i + 3], w.w, acc);
+        }
+        tileP[j * kTP + lane] = acc;  // pre-activation
+        const float hj = fmaxf(acc, 0.f);
+        const float4 w2 = *reinterpret_cast<const float4 *>(lds_w + kOffW2T + j * 4);
+        o[0] = fmaf(hj, w2.x, o[0]);
+        o[1] = fmaf(hj, w2.y, o[1]);
+        o[2] = fmaf(hj, w2.z, o[2]);
+      }
+    }
 
     float d_o[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      const float s = 1.f / (1.f + expf(-o[c]));
+      const float sg = 1.f / (1.f + expf(-o[c]));
       const float g = valid ? d_rgb[3 * pc + c] : 0.f;
-      d_o[c] = g * (1.f + 2.f * kEps) * s * (1.f - s);
+      d_o[c] = g * (1.f + 2.f * kEps) * sg * (1.f - sg);
       acc_b2[c] += d_o[c];
     }
-    // weight rows are walked contiguously (c / j / i outer, row elements inner) so that the scalar
-    // loads stay s_load_dwordx16
-    float d_hid[kHid];
-#pragma unroll
-    for (int j = 0; j < kHid; j++) d_hid[j] = d_o[0] * P.w2[j];
-#pragma unroll
-    for (int c = 1; c < 3; c++) {
-#pragma unroll
-      for (int j = 0; j < kHid; j++) d_hid[j] = fmaf(d_o[c], P.w2[c * kHid + j], d_hid[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < kHid; j++) d_hid[j] = (pre[j] > 0.f) ? d_hid[j] : 0.f;
-    float d_h[kOut1];  // d_h[i] for i >= 1 equals dX[i]; dX[0] only feeds the embedding
-    float dX0;
-    {
-      float dX[kOut1];
-#pragma unroll
-      for (int i = 0; i < kOut1; i++) dX[i] = 0.f;
-#pragma unroll
-      for (int j = 0; j < kHid; j++) {
-#pragma unroll
-        for (int i = 0; i < kOut1; i++) dX[i] = fmaf(d_hid[j], P.w1[j * kIn2 + i], dX[i]);
-      }
-      dX0 = dX[0];
-      d_h[0] = valid ? d_logit[pc] : 0.f;
-#pragma unroll
-      for (int i = 1; i < kOut1; i++) d_h[i] = dX[i];
-    }
-#pragma unroll
-    for (int i = 0; i < kOut1; i++) acc_bh[i] += d_h[i];
-    {
-      float d_e[C];
-#pragma unroll
-      for (int c = 0; c < C; c++) d_e[c] = d_h[0] * P.w_h[c];
-#pragma unroll
-      for (int i = 1; i < kOut1; i++) {
-#pragma unroll
-        for (int c = 0; c < C; c++) d_e[c] = fmaf(d_h[i], P.w_h[i * C + c], d_e[c]);
-      }
-      if (valid) {
-#pragma unroll
-        for (int c = 0; c < C; c++) d_enc[(int64_t)c * n + p] = d_e[c];
-      }
-    }
 
-    // ---- phase A: d w1[j][i] += sum_s d_hid[s][j] * X[s][i] ; d b1[j] += sum_s d_hid[s][j]
-#pragma unroll
-    for (int j = 0; j < kHid; j += 4)
-      *reinterpret_cast<float4 *>(tileA + lane * kStrideA + j) =
-        make_float4(d_hid[j], d_hid[j + 1], d_hid[j + 2], d_hid[j + 3]);
-#pragma unroll
-    for (int i = 0; i < kIn2; i += 4)
-      *reinterpret_cast<float4 *>(tileB + lane * kStrideB + i) =
-        make_float4(X[i], X[i + 1], X[i + 2], X[i + 3]);
+    // ---- 2. d w2[c][j] += sum_s d_o[s][c] * relu(pre[s][j])     (lane = j)
+    *reinterpret_cast<float4 *>(tileX + lane * 4) = make_float4(d_o[0], d_o[1], d_o[2], 0.f);
     wave_lds_sync();
 #pragma unroll 4
     for (int s = 0; s < 64; s++) {
-      const float a = tileA[s * kStrideA + lane];
+      const float a = fmaxf(tileP[lane * kTP + s], 0.f);
+      const float4 g = *reinterpret_cast<const float4 *>(tileX + s * 4);
+      acc_w2[0] = fmaf(g.x, a, acc_w2[0]);
+      acc_w2[1] = fmaf(g.y, a, acc_w2[1]);
+      acc_w2[2] = fmaf(g.z, a, acc_w2[2]);
+    }
+    wave_lds_sync();
+
+    // ---- 3. back through the hidden layer (lane = sample): d_hid replaces pre in the tile
+    float dX[kOut1];
+#pragma unroll
+    for (int i = 0; i < kOut1; i++) dX[i] = 0.f;
+#pragma unroll 2
+    for (int j = 0; j < kHid; j++) {
+      const float pre = tileP[j * kTP + lane];
+      const float4 w2 = *reinterpret_cast<const float4 *>(lds_w + kOffW2T + j * 4);
+      float dh = d_o[0] * w2.x;
+      dh = fmaf(d_o[1], w2.y, dh);
+      dh = fmaf(d_o[2], w2.z, dh);
+      dh = (pre > 0.f) ? dh : 0.f;
+      tileP[j * kTP + lane] = dh;
+      const float * row = lds_w + kOffW1 + j * kW1P;
+#pragma unroll
+      for (int i = 0; i < kOut1; i += 4) {  // only the 16 non-SH input columns carry gradient
+        const float4 w = *reinterpret_cast<const float4 *>(row + i);
+        dX[i] = fmaf(dh, w.x, dX[i]);
+        dX[i + 1] = fmaf(dh, w.y, dX[i + 1]);
+        dX[i + 2] = fmaf(dh, w.z, dX[i + 2]);
+        dX[i + 3] = fmaf(dh, w.w, dX[i + 3]);
+      }
+    }
+    // d_h: gradient w.r.t. the 16 head outputs; dX[0] only feeds the embedding (X[0] = 1 + emb[0])
+    float d_h[kOut1];
+    d_h[0] = valid ? d_logit[pc] : 0.f;
+#pragma unroll
+    for (int i = 1; i < kOut1; i++) d_h[i] = dX[i];
+#pragma unroll
+    for (int i = 0; i < kOut1; i++) acc_bh[i] += d_h[i];
+
+    // ---- 4. d w1[j][i] += sum_s d_hid[s][j] * X[s][i] ; d b1[j] += sum_s d_hid[s][j]   (lane = j)
+#pragma unroll
+    for (int i = 0; i < kIn2; i += 4)
+      *reinterpret_cast<float4 *>(tileX + lane * kXP + i) =
+        make_float4(X[i], X[i + 1], X[i + 2], X[i + 3]);
+    wave_lds_sync();
+#pragma unroll 2
+    for (int s = 0; s < 64; s++) {
+      const float a = tileP[lane * kTP + s];
       acc_b1 += a;
 #pragma unroll
       for (int i = 0; i < kIn2; i += 4) {
-        const float4 x = *reinterpret_cast<const float4 *>(tileB + s * kStrideB + i);
+        const float4 x = *reinterpret_cast<const float4 *>(tileX + s * kXP + i);
         acc_w1[i] = fmaf(a, x.x, acc_w1[i]);
         acc_w1[i + 1] = fmaf(a, x.y, acc_w1[i + 1]);
         acc_w1[i + 2] = fmaf(a, x.z, acc_w1[i + 2]);
@@ -269,79 +331,82 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
     }
     wave_lds_sync();
 
-    // ---- phase B: d w2[c][j] += sum_s d_o[s][c] * relu(pre[s][j])
-#pragma unroll
-    for (int j = 0; j < kHid; j += 4)
-      *reinterpret_cast<float4 *>(tileA + lane * kStrideA + j) = make_float4(
-        fmaxf(pre[j], 0.f), fmaxf(pre[j + 1], 0.f), fmaxf(pre[j + 2], 0.f), fmaxf(pre[j + 3], 0.f));
-    *reinterpret_cast<float4 *>(tileB + lane * 4) = make_float4(d_o[0], d_o[1], d_o[2], 0.f);
-    wave_lds_sync();
-#pragma unroll 8
-    for (int s = 0; s < 64; s++) {
-      const float a = tileA[s * kStrideA + lane];
-      const float4 g = *reinterpret_cast<const float4 *>(tileB + s * 4);
-      acc_w2[0] = fmaf(g.x, a, acc_w2[0]);
-      acc_w2[1] = fmaf(g.y, a, acc_w2[1]);
-      acc_w2[2] = fmaf(g.z, a, acc_w2[2]);
-    }
-    wave_lds_sync();
-
-    // ---- phase C: d w_h[i][c] += sum_s d_h[s][i] * enc[s][c]
+    // ---- 5a. d_enc[c] = sum_i d_h[i] * w_h[i][c]
     {
-      constexpr int kStrideE = C + 4;
-      constexpr int kStrideH = kOut1 + 4;
+      float d_e[C];
+#pragma unroll
+      for (int c = 0; c < C; c++) d_e[c] = 0.f;
+      // d_h through LDS ([i][64] columns) so the rolled loop over i needs no dynamic register index
+#pragma unroll
+      for (int i = 0; i < kOut1; i++) tileP[i * 64 + lane] = d_h[i];
+#pragma unroll 2
+      for (int i = 0; i < kOut1; i++) {
+        const float a = tileP[i * 64 + lane];
+        const float * row = lds_w + kOffWh + i * kWhP;
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+          const float4 w = *reinterpret_cast<const float4 *>(row + c);
+          d_e[c] = fmaf(a, w.x, d_e[c]);
+          d_e[c + 1] = fmaf(a, w.y, d_e[c + 1]);
+          d_e[c + 2] = fmaf(a, w.z, d_e[c + 2]);
+          d_e[c + 3] = fmaf(a, w.w, d_e[c + 3]);
+        }
+      }
+      if (valid) {
+#pragma unroll
+        for (int c = 0; c < C; c++) d_enc[(int64_t)c * n + p] = d_e[c];
+      }
+    }
+
+    // ---- 5b. d w_h[i][c] += sum_s d_h[s][i] * enc[s][c]
+    {
+      constexpr int kEP = C + 4;       // [sample][C] rows in tileP (C <= 64)
+      constexpr int kHP = kOut1 + 4;   // [sample][16] rows in tileX
+      wave_lds_sync();
 #pragma unroll
       for (int c = 0; c < C; c += 4)
-        *reinterpret_cast<float4 *>(tileA + lane * kStrideE + c) =
+        *reinterpret_cast<float4 *>(tileP + lane * kEP + c) =
           make_float4(e[c], e[c + 1], e[c + 2], e[c + 3]);
+      // row of {dX[0] (embedding only), d_h[1..15]} plus d_h[0] in the pad slot
+      *reinterpret_cast<float4 *>(tileX + lane * kHP) =
+        make_float4(valid ? dX[0] : 0.f, d_h[1], d_h[2], d_h[3]);
 #pragma unroll
-      for (int i = 0; i < kOut1; i += 4)
-        *reinterpret_cast<float4 *>(tileB + lane * kStrideH + i) =
+      for (int i = 4; i < kOut1; i += 4)
+        *reinterpret_cast<float4 *>(tileX + lane * kHP + i) =
           make_float4(d_h[i], d_h[i + 1], d_h[i + 2], d_h[i + 3]);
+      tileX[lane * kHP + kOut1] = d_h[0];
       wave_lds_sync();
       const int wi = lane & 15, wq = lane >> 4;
+      const int col = (wi == 0) ? kOut1 : wi;  // head output 0's gradient lives in the pad slot
 #pragma unroll 4
       for (int s = 0; s < 64; s++) {
-        const float a = tileB[s * kStrideH + wi];
+        const float a = tileX[s * kHP + col];
 #pragma unroll
         for (int k = 0; k < CQ; k += 4) {
-          const float4 x = *reinterpret_cast<const float4 *>(tileA + s * kStrideE + wq * CQ + k);
+          const float4 x = *reinterpret_cast<const float4 *>(tileP + s * kEP + wq * CQ + k);
           acc_wh[k] = fmaf(a, x.x, acc_wh[k]);
           if (k + 1 < CQ) acc_wh[k + 1] = fmaf(a, x.y, acc_wh[k + 1]);
           if (k + 2 < CQ) acc_wh[k + 2] = fmaf(a, x.z, acc_wh[k + 2]);
           if (k + 3 < CQ) acc_wh[k + 3] = fmaf(a, x.w, acc_wh[k + 3]);
         }
       }
-      wave_lds_sync();
-    }
-
-    // ---- phase D: appearance embedding, d emb[img][i] += dX[i] (i = 0 included: X[0] = 1 + emb[0])
-    if (has_emb) {
-      const int img0 = __builtin_amdgcn_readfirstlane(img);
-      const bool uniform = __all(img == img0);
-      if (uniform) {
-        constexpr int kStrideH = kOut1 + 4;
-        *reinterpret_cast<float4 *>(tileB + lane * kStrideH) =
-          make_float4(valid ? dX0 : 0.f, d_h[1], d_h[2], d_h[3]);
+      // ---- 5c. appearance embedding: d emb[img][i] += dX[i]
+      if (has_emb) {
+        const int img0 = __builtin_amdgcn_readfirstlane(img);
+        if (__all(img == img0)) {
+          // lane (i = lane&15, part = lane>>4) sums 16 of the 64 samples, then the 4 parts combine
+          float part = 0.f;
 #pragma unroll
-        for (int i = 4; i < kOut1; i += 4)
-          *reinterpret_cast<float4 *>(tileB + lane * kStrideH + i) =
-            make_float4(d_h[i], d_h[i + 1], d_h[i + 2], d_h[i + 3]);
-        wave_lds_sync();
-        // lane (i = lane&15, part = lane>>4) sums 16 of the 64 samples, then the 4 parts combine
-        float part = 0.f;
-        const int ei = lane & 15, eq = lane >> 4;
+          for (int s = 0; s < 16; s++) part += tileX[(wq * 16 + s) * kHP + wi];
+          part += __shfl_xor(part, 16);
+          part += __shfl_xor(part, 32);
+          if (lane < 16) atomicAdd(g_emb + (int64_t)img0 * kOut1 + lane, part);
+        } else if (valid) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) part += tileB[(eq * 16 + s) * kStrideH + ei];
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        if (lane < 16) atomicAdd(g_emb + (int64_t)img0 * kOut1 + lane, part);
-        wave_lds_sync();
-      } else if (valid) {
-        atomicAdd(g_emb + (int64_t)img * kOut1, dX0);
-#pragma unroll
-        for (int i = 1; i < kOut1; i++) atomicAdd(g_emb + (int64_t)img * kOut1 + i, d_h[i]);
+          for (int i = 0; i < kOut1; i++) atomicAdd(g_emb + (int64_t)img * kOut1 + i, dX[i]);
+        }
       }
+      wave_lds_sync();
     }
   }
 
