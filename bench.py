@@ -86,6 +86,8 @@ def algorithmic_bytes(kernel, L, F, S):
         return 12 + 4 * L * F + 16 * L * F
     if kernel == "density_march":  # per ray (dense regime): o,d in, S x (noise + 8 corners x F f16 x L), count out
         return 24 + S * (4 + 16 * L * F) + 4
+    if kernel == "density_scan":   # per ray: S x (L*F f32 features + dt) in, count out
+        return S * (4 * L * F + 4) + 4
     raise KeyError(kernel)
 
 

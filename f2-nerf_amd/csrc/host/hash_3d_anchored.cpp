@@ -160,6 +160,19 @@ Tensor Hash3DAnchored::encode(const Tensor & points)
   return torch::autograd::Hash3DAnchoredFunction::apply(x, feat_pool_, torch::IValue(info))[0];
 }
 
+Tensor Hash3DAnchored::encode_cached(const Tensor & points, const Tensor & enc_cm)
+{
+  TORCH_CHECK(
+    enc_cm.dim() == 2 && enc_cm.is_contiguous() && enc_cm.size(1) == points.size(0) &&
+      enc_cm.size(0) == options_.n_levels * options_.n_channels,
+    "encode_cached: enc_cm must be contiguous [L*F, n]");
+  auto info = torch::make_intrusive<Hash3DAnchoredInfo>();
+  info->hash3d_ = this;
+  info->precomputed_cm_ = enc_cm;
+  Tensor x = ContractFn::apply(points)[0];
+  return torch::autograd::Hash3DAnchoredFunction::apply(x, feat_pool_, torch::IValue(info))[0];
+}
+
 Tensor Hash3DAnchored::query(const Tensor & points)
 {
   return mlp_->forward(encode(points));
@@ -194,6 +207,7 @@ variable_list Hash3DAnchoredFunction::forward(
 
   const int64_t n = points.size(0);
   const int L = (int)field->options_.n_levels, F = (int)field->options_.n_channels;
+  if (info->precomputed_cm_.defined()) return {info->precomputed_cm_.t()};
   Tensor table16 = field->table_for(feat_pool);
   // f32 tensor holding f16-rounded values (the reference's out_feat.to(kFloat32), fused).  Storage
   // is channel-major [L*F, n] -- every wavefront store is one coalesced 256-byte row segment instead

@@ -42,6 +42,11 @@ public:
   // fused path feeds this straight into the fused per-sample network kernel.
   Tensor encode(const Tensor & points);
 
+  // Same autograd node as encode(), but the forward result is supplied: `enc_cm` [L*F, n]
+  // channel-major, the encoding of exactly these points computed earlier (the Renderer's first pass).
+  // Only the backward (table gradient) runs a kernel.
+  Tensor encode_cached(const Tensor & points, const Tensor & enc_cm);
+
   // Row 0 of mlp_ (weight [L*F], bias [1]) as contiguous device tensors: the density head the fused
   // ray march evaluates in-kernel.
   std::pair<Tensor, Tensor> density_head() const;
@@ -75,6 +80,7 @@ class Hash3DAnchoredInfo : public torch::CustomClassHolder
 {
 public:
   Hash3DAnchored * hash3d_ = nullptr;
+  torch::Tensor precomputed_cm_;  // optional [L*F, n] encoding to return instead of computing it
 };
 
 namespace torch::autograd

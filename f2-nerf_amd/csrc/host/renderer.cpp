@@ -72,6 +72,73 @@ RenderResult Renderer::render_fused(
   Hash3DAnchored & field = *scene_field_;
   const int L = (int)field.options_.n_levels, F = (int)field.options_.n_channels;
 
+  const int64_t C = (int64_t)L * F;
+  const bool dense_ok = options_.fused_shade && f2n::shade_supported(C) &&
+                        field.options_.mlp_out_dim == 16;
+  const bool dense = dense_ok && (options_.dense_first_pass == 1 ||
+                                  (options_.dense_first_pass < 0 && last_kept_fraction_ > 0.4f));
+  if (dense) {
+    // Dense first pass: every sample is encoded once (level-major kernel), the keep-prefix comes
+    // from that encoding, and the shading pass reuses it -- same counts as the march, bit for bit.
+    SampleResultFlex all = pts_sampler_->get_samples(rays_o, rays_d, noise);
+    const int64_t n_all = all.pts.size(0);
+    SampleResultFlex kept;
+    Tensor enc_kept_cm;
+    {
+      torch::NoGradGuard no_grad;
+      Tensor enc_all_cm = field.encode(all.pts).t();  // [C, n_all] contiguous storage
+      TORCH_CHECK(enc_all_cm.is_contiguous(), "encode() must return channel-major storage");
+      auto head = field.density_head();
+      Tensor counts = torch::empty({n_rays}, iopt);
+      {
+        f2n::ScopedKernelTimer timer("density_scan", stream, (double)n_rays);
+        f2n::check(
+          f2n_density_scan(
+            enc_all_cm.data_ptr<float>(), (int)C, all.dt.data_ptr<float>(),
+            head.first.data_ptr<float>(), head.second.data_ptr<float>(),
+            counts.data_ptr<int32_t>(), n_rays, S, options_.early_stop_trans, 3.f, stream),
+          "f2n_density_scan");
+      }
+      kept.pts_idx_bounds = torch::empty({n_rays, 2}, iopt);
+      Tensor total = torch::empty({1}, iopt);
+      f2n::check(
+        f2n_bounds_from_counts(
+          counts.data_ptr<int32_t>(), kept.pts_idx_bounds.data_ptr<int32_t>(),
+          total.data_ptr<int32_t>(), n_rays, stream),
+        "f2n_bounds_from_counts");
+      const int64_t n_kept = total.item<int>();
+      last_n_samples_ = n_kept;
+      last_kept_fraction_ = n_all > 0 ? (float)n_kept / (float)n_all : 0.f;
+      if (n_kept == n_all) {
+        // nothing terminated: the uncompacted arrays ARE the compacted ones
+        kept.pts = all.pts;
+        kept.dirs = all.dirs;
+        kept.dt = all.dt;
+        kept.t = all.t;
+        enc_kept_cm = enc_all_cm;
+      } else {
+        kept.pts = torch::empty({n_kept, 3}, fopt);
+        kept.dirs = torch::empty({n_kept, 3}, fopt);
+        kept.dt = torch::empty({n_kept}, fopt);
+        kept.t = torch::empty({n_kept}, fopt);
+        f2n::check(
+          f2n_sample_compact(
+            rays_o.data_ptr<float>(), rays_d.data_ptr<float>(), f2n::fptr(noise),
+            kept.pts_idx_bounds.data_ptr<int32_t>(), kept.pts.data_ptr<float>(),
+            kept.dirs.data_ptr<float>(), kept.dt.data_ptr<float>(), kept.t.data_ptr<float>(),
+            n_rays, S, step, stream),
+          "f2n_sample_compact");
+        enc_kept_cm = torch::empty({C, n_kept}, fopt);
+        f2n::check(
+          f2n_compact_rows_cm(
+            enc_all_cm.data_ptr<float>(), n_all, enc_kept_cm.data_ptr<float>(), n_kept, (int)C,
+            kept.pts_idx_bounds.data_ptr<int32_t>(), n_rays, S, stream),
+          "f2n_compact_rows_cm");
+      }
+    }
+    return shade_and_composite(kept, emb_idx, mode, bg_color, enc_kept_cm);
+  }
+
   SampleResultFlex kept;
   {
     // First pass (renderer.cpp:58-90): density only, never differentiated by the loss.
@@ -100,6 +167,7 @@ RenderResult Renderer::render_fused(
       "f2n_bounds_from_counts");
     const int64_t n_kept = total.item<int>();  // the one host sync of the fused path (sizes tensors)
     last_n_samples_ = n_kept;
+    last_kept_fraction_ = (float)n_kept / (float)((int64_t)n_rays * S);
     kept.pts = torch::empty({n_kept, 3}, fopt);
     kept.dirs = torch::empty({n_kept, 3}, fopt);
     kept.dt = torch::empty({n_kept}, fopt);
@@ -117,13 +185,15 @@ RenderResult Renderer::render_fused(
 
 // Second pass on the survivors (renderer.cpp:92-118).
 RenderResult Renderer::shade_and_composite(
-  const SampleResultFlex & kept, const Tensor & emb_idx, RunningMode mode, const Tensor & bg_color)
+  const SampleResultFlex & kept, const Tensor & emb_idx, RunningMode mode, const Tensor & bg_color,
+  const Tensor & enc_cm)
 {
   const int64_t n_kept = kept.pts.size(0);
   const int64_t C = scene_field_->options_.n_levels * scene_field_->options_.n_channels;
   if (options_.fused_shade && f2n::shade_supported(C) && scene_field_->options_.mlp_out_dim == 16) {
     // hash encode -> one kernel for field head + embedding + SH + colour MLP -> composite
-    Tensor enc = scene_field_->encode(kept.pts);
+    Tensor enc = enc_cm.defined() ? scene_field_->encode_cached(kept.pts, enc_cm)
+                                  : scene_field_->encode(kept.pts);
     Tensor sample_img;
     if (mode == RunningMode::TRAIN)
       sample_img = CustomOps::ScatterIdx((int)n_kept, kept.pts_idx_bounds, emb_idx);

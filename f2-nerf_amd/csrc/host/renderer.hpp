@@ -37,6 +37,12 @@ struct RendererOptions
   PtsSamplerOptions sampler;
   bool fused = true;
   bool fused_shade = true;         // per-sample network as one kernel (needs L*F in {8,16,32,64})
+  // First-pass strategy of the fused path: -1 = adaptive (dense when the previous call kept more
+  // than 40 % of its samples), 0 = always the early-terminating march, 1 = always dense.
+  // dense: encode ALL samples once with the level-major kernel, derive the keep-prefix from that
+  // encoding and hand the (compacted) encoding to the shading pass, so the field is evaluated once
+  // instead of twice when little terminates; march: stop rays in-kernel, re-encode survivors.
+  int dense_first_pass = -1;
   float early_stop_trans = 1e-4f;  // renderer.cpp:68
   bool check_finite = false;       // the reference's CHECK(isfinite(colors.mean())) host sync
 };
@@ -73,6 +79,7 @@ public:
   Tensor app_emb_;
 
   int64_t last_n_samples_ = 0;  // survivors of the most recent render() (bench bookkeeping)
+  float last_kept_fraction_ = 0.f;
 
 private:
   RenderResult render_fused(
@@ -83,7 +90,7 @@ private:
     const Tensor & noise, const Tensor & bg_color);
   RenderResult shade_and_composite(
     const SampleResultFlex & kept, const Tensor & emb_idx, RunningMode mode,
-    const Tensor & bg_color);
+    const Tensor & bg_color, const Tensor & enc_cm = Tensor());
 };
 
 namespace f2n

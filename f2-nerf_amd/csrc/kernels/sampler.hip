@@ -208,6 +208,64 @@ __global__ __launch_bounds__(F2N_BLOCK) void density_march_kernel(
   if (lane == 0) kept[r] = n_kept;
 }
 
+// ---- f2n_density_scan ---------------------------------------------------------------------------
+// The keep-prefix of every ray from an ALREADY COMPUTED encoding of all its samples (channel-major
+// [C, n_all]): same logit FMA chain, same scan and same threshold test as density_march_kernel, so
+// both give identical counts.  Used when most samples survive anyway: the encoding is then computed
+// once by the level-major f2n_hash_fwd (L2-resident table levels) and reused by the shading pass,
+// instead of being evaluated by the march and again by the second pass.
+template <int C>
+__global__ __launch_bounds__(F2N_BLOCK) void density_scan_kernel(
+  const float * __restrict__ enc, const float * __restrict__ dt, const float * __restrict__ w0,
+  const float * __restrict__ b0, int32_t * __restrict__ kept, int n_rays, int S, int64_t n_all,
+  float t_thresh, float density_shift)
+{
+  const int r = ray_of_wave();
+  if (r >= n_rays) return;
+  const int lane = lane_id();
+  const float bias0 = b0[0];
+  const int64_t base = (int64_t)r * S;
+  float depth_carry = 0.f;
+  int n_kept = 0;
+  for (int k0 = 0; k0 < S; k0 += F2N_WAVE) {
+    const int k = k0 + lane;
+    const bool valid = k < S;
+    const int64_t i = base + (valid ? k : S - 1);
+    float logit = bias0;
+#pragma unroll
+    for (int c = 0; c < C; c++) logit = fmaf(enc[(int64_t)c * n_all + i], w0[c], logit);
+    const float sigma = expf(logit - density_shift);
+    const float sec = valid ? sigma * dt[i] : 0.f;
+    const float incl = wave_incl_scan(sec);
+    const float depth = depth_carry + wave_shift_up1(incl, 0.f);
+    const float trans = expf(-depth);
+    const bool keep = valid && (trans > t_thresh);
+    const unsigned long long m = __ballot(keep);
+    n_kept += __popcll(m);
+    const int n_valid = min(F2N_WAVE, S - k0);
+    if (__popcll(m) < n_valid) break;
+    depth_carry += wave_bcast_last(incl);
+  }
+  if (lane == 0) kept[r] = n_kept;
+}
+
+// ---- f2n_compact_rows_cm ------------------------------------------------------------------------
+// Channel-major compaction of per-ray prefixes: dst[c, new_start_r + k] = src[c, r*S + k], k < cnt_r.
+__global__ __launch_bounds__(F2N_BLOCK) void compact_rows_cm_kernel(
+  const float * __restrict__ src, int64_t n_src, float * __restrict__ dst, int64_t n_dst, int C,
+  const int32_t * __restrict__ bounds, int n_rays, int S)
+{
+  const int r = ray_of_wave();
+  if (r >= n_rays) return;
+  const int lane = lane_id();
+  const int start = bounds[2 * r];
+  const int cnt = bounds[2 * r + 1] - start;
+  const int64_t sbase = (int64_t)r * S;
+  for (int k = lane; k < cnt; k += F2N_WAVE)
+    for (int c = 0; c < C; c++)
+      dst[(int64_t)c * n_dst + start + k] = src[(int64_t)c * n_src + sbase + k];
+}
+
 // ---- f2n_bounds_from_counts ---------------------------------------------------------------------
 
 constexpr int kScanBlock = 1024;
@@ -314,6 +372,45 @@ extern "C" int f2n_density_march(
     default: if (p2) F2N_MARCH(8, true); else F2N_MARCH(8, false); break;
   }
 #undef F2N_MARCH
+  return f2n_launch_status();
+}
+
+extern "C" int f2n_density_scan(
+  const float * enc_cm, int C, const float * dt, const float * w0, const float * b0, int32_t * kept,
+  int n_rays, int S, float t_thresh, float density_shift, void * stream)
+{
+  if (n_rays < 0 || S < 1) return F2N_E_INVALID_ARG;
+  if (C != 8 && C != 16 && C != 32 && C != 64 && C != 128) return F2N_E_UNSUPPORTED;
+  if (n_rays == 0) return F2N_OK;
+  if (!enc_cm || !dt || !w0 || !b0 || !kept) return F2N_E_INVALID_ARG;
+  const dim3 grid(f2n_div_up(n_rays, F2N_WAVES_PER_BLOCK)), block(F2N_BLOCK);
+  const int64_t n_all = (int64_t)n_rays * S;
+  hipStream_t s = (hipStream_t)stream;
+#define F2N_SCAN(CC)                                                                              \
+  hipLaunchKernelGGL(                                                                             \
+    (density_scan_kernel<CC>), grid, block, 0, s, enc_cm, dt, w0, b0, kept, n_rays, S, n_all,     \
+    t_thresh, density_shift)
+  switch (C) {
+    case 8: F2N_SCAN(8); break;
+    case 16: F2N_SCAN(16); break;
+    case 32: F2N_SCAN(32); break;
+    case 64: F2N_SCAN(64); break;
+    default: F2N_SCAN(128); break;
+  }
+#undef F2N_SCAN
+  return f2n_launch_status();
+}
+
+extern "C" int f2n_compact_rows_cm(
+  const float * src, int64_t n_src, float * dst, int64_t n_dst, int C, const int32_t * bounds,
+  int n_rays, int S, void * stream)
+{
+  if (n_rays < 0 || S < 1 || C < 1 || n_src < 0 || n_dst < 0) return F2N_E_INVALID_ARG;
+  if (n_rays == 0 || n_dst == 0) return F2N_OK;
+  if (!src || !dst || !bounds) return F2N_E_INVALID_ARG;
+  hipLaunchKernelGGL(
+    compact_rows_cm_kernel, dim3(f2n_div_up(n_rays, F2N_WAVES_PER_BLOCK)), dim3(F2N_BLOCK), 0,
+    (hipStream_t)stream, src, n_src, dst, n_dst, C, bounds, n_rays, S);
   return f2n_launch_status();
 }
 

@@ -157,6 +157,22 @@ int f2n_density_march(
   int32_t * kept, int n_rays, int S, float step, int L, int F, uint32_t T, int64_t level_stride,
   float t_thresh, float density_shift, void * stream);
 
+/* The same keep-prefix as f2n_density_march (src/renderer.cpp:61-68 semantics), computed from an
+ * encoding that already exists for ALL n_rays*S samples: enc_cm channel-major [C, n_rays*S] as
+ * f2n_hash_fwd writes it, dt [n_rays*S] as f2n_sample_rays writes it.  Identical FMA chain, scan and
+ * threshold test, hence identical counts.  The host picks this route when most samples survive, so
+ * that the field is evaluated once (level-major, L2-friendly) and reused by the shading pass --
+ * the reference evaluates it twice (src/renderer.cpp:61 and :92). */
+int f2n_density_scan(
+  const float * enc_cm, int C, const float * dt, const float * w0, const float * b0, int32_t * kept,
+  int n_rays, int S, float t_thresh, float density_shift, void * stream);
+
+/* Channel-major companion of the four index() gathers at src/renderer.cpp:71-74 for [C, n] tensors:
+ * dst[c, bounds[r].start + k] = src[c, r*S + k] for k < bounds[r].end - bounds[r].start. */
+int f2n_compact_rows_cm(
+  const float * src, int64_t n_src, float * dst, int64_t n_dst, int C, const int32_t * bounds,
+  int n_rays, int S, void * stream);
+
 /* cumsum of the per-ray counts -> bounds (src/renderer.cpp:76-83).  total[0] = sum(kept).
  * Single-workgroup scan; n_rays <= 2^24. */
 int f2n_bounds_from_counts(

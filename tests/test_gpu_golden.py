@@ -74,9 +74,11 @@ def test_render_against_golden(dev):
         for k, v in ren.named_parameters().items():
             v.copy_(z["param." + k].to(dev))
     to = lambda k: z[k].to(dev)
-    for fused, fused_shade in ((True, True), (True, False), (False, False)):
+    for fused, fused_shade, dense in ((True, True, 0), (True, True, 1), (True, False, 0),
+                                      (False, False, 0)):
         ren.set_fused(fused)
         ren.set_fused_shade(fused_shade)
+        ren.set_dense_first_pass(dense)
         ren.zero_grad()
         c, d, w, idx = ren.render(to("rays_o"), to("rays_d"), to("emb_idx"), "train", to("noise"),
                                   to("bg"))

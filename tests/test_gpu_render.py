@@ -89,9 +89,11 @@ def test_train_step_matches_oracle(host, dev, L, F, log2_T, S, step, bias0):
 
     to = lambda x: x.to(dev)
     # fused march + fused per-sample network | fused march + ATen MLPs | the reference's op sequence
-    for fused, fused_shade in ((True, True), (True, False), (False, False)):
+    for fused, fused_shade, dense in ((True, True, 0), (True, True, 1), (True, False, 0),
+                                      (False, False, 0)):
         hr.set_fused(fused)
         hr.set_fused_shade(fused_shade)
+        hr.set_dense_first_pass(dense)   # 0 = early-terminating march, 1 = encode-once dense pass
         hr.zero_grad()
         colors, depths, weights, idx = hr.render(to(o), to(d), to(emb), "train", to(noise), to(bg))
         assert torch.equal(idx.cpu(), res.idx_start_end), "kept-prefix bounds differ"
