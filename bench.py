@@ -91,6 +91,34 @@ def algorithmic_bytes(kernel, L, F, S):
     raise KeyError(kernel)
 
 
+# kernels behind each hipEvent-timed operator, for the PMC traffic lookup
+OP_KERNELS = {
+    "hash_fwd": ["hash_fwd_kernel"],
+    "hash_bwd": ["hash_bwd_bin_kernel", "hash_bwd_reduce_kernel"],
+    "density_march": ["density_march_kernel"],
+    "density_scan": ["density_scan_kernel"],
+}
+
+
+def pmc_traffic_bytes(op):
+    """HBM-side bytes per launch of `op` from the newest committed rocprofv3 --pmc summary
+    (profiles/r*_pmc_traffic.json, made by tools/pmc_summary.py from separate FETCH_SIZE and
+    WRITE_SIZE passes of this same command; FETCH_SIZE doubled as the gfx950 guide prescribes).
+    PMC counters cannot be read inside the timed run, so this is a lookup, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        tot = 0.0
+        for k in OP_KERNELS.get(op, []):
+            tot += d[k].get("read_bytes_corrected", 0.0) + d[k].get("write_bytes", 0.0)
+        return tot or None
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def usable_cores():
     """Host cores this process may actually run on: affinity mask, capped by the cgroup CPU quota."""
     try:
@@ -259,7 +287,10 @@ def main():
         if dom:
             a = kernels[dom]["achieved_GBs"]
             roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None}
+                        "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dom),
+                        "algorithmic_bytes_per_launch": kernels[dom]["units_per_launch"] *
+                        kernels[dom]["algorithmic_bytes_per_unit"],
+                        "avg_launch_ms": kernels[dom]["avg_ms"]}
         out = {
             "metric": "rendered rays/sec (fwd+bwd) at 800x800",
             "value": rays_total / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,

@@ -424,9 +424,10 @@ __global__ __launch_bounds__(kSliceBlock) void hash_bwd_reduce_kernel(
           const bool live = (j0 + u) < n_here;
           if (!live) cnt[u] = 0u;
           const uint32_t * region = base + (size_t)(t0 + (live ? j0 + u : 0)) * tile_stride;
-          // unconditional load (the whole region is allocated): no branch, so the four loads are
-          // in flight together; slots >= cnt hold garbage and are skipped below
-          const uint32_t i = min((uint32_t)(lane + 64 * h), (uint32_t)(qcap - 1));
+          // branch-free load so the four loads are in flight together: lanes past the region's
+          // count re-read its last record (same cache lines, no extra traffic) and skip it below
+          const uint32_t last = cnt[u] ? cnt[u] - 1u : 0u;
+          const uint32_t i = min((uint32_t)(lane + 64 * h), last);
           if constexpr (RW == 2) {
             const uint2 r = *reinterpret_cast<const uint2 *>(region + (size_t)i * 2);
             rec[u][0] = r.x;

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection.csv files per kernel (average per dispatch).
+
+  python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/rNN_pmc.json
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
+(MI355X_MICROARCH.md, HBM section): `read_bytes_corrected` applies that factor; gather-dominated
+kernels are uncalibrated, so both raw and corrected values are kept.
+"""
+import csv
+import glob
+import json
+import re
+import sys
+from collections import defaultdict
+
+csv.field_size_limit(1 << 30)
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel)\b", name)
+    if m and "anonymous" in name:
+        return m.group(1)
+    return None
+
+
+def main(dirs):
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for d in dirs:
+        for f in glob.glob(d + "/*/*counter_collection.csv"):
+            for row in csv.DictReader(open(f)):
+                k = short(row["Kernel_Name"])
+                if not k:
+                    continue
+                a = acc[k][row["Counter_Name"]]
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+                t = acc[k]["duration_us"]
+                t[0] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+                t[1] += 1
+    out = {}
+    for k, cs in sorted(acc.items()):
+        e = {"dispatches": max(v[1] for v in cs.values())}
+        for c, (tot, n) in cs.items():
+            e[c + "_avg"] = tot / n
+        if "FETCH_SIZE_avg" in e:
+            e["read_bytes_raw"] = e["FETCH_SIZE_avg"] * 1024
+            e["read_bytes_corrected"] = e["FETCH_SIZE_avg"] * 2048
+        if "WRITE_SIZE_avg" in e:
+            e["write_bytes"] = e["WRITE_SIZE_avg"] * 1024
+        out[k] = e
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
