@@ -48,6 +48,13 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=2048)
     ap.add_argument("--n-images", type=int, default=50)
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend; nccl = RCCL (default). 'gloo' + --share-gpu lets "
+                         "several ranks rehearse the multi-rank path on a one-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--rays", type=int, default=0,
+                    help="rays per step per GPU instead of a full view (e.g. 512 = BASELINE config C4 "
+                         "with --samples 1024); pixels drawn at random like dataset.cpp:153-155")
     return ap.parse_args()
 
 
@@ -190,21 +197,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
     pkg = importlib.import_module("f2-nerf_amd")
     H = pkg.load_host()
     H.manual_seed(2022)          # reference main.cpp:11; identical parameters on every rank
     torch.manual_seed(2022)
     S, L, F = args.samples, args.levels, args.channels
+    step_len = 1.0 / 256 if S == 1024 else 4.0 / S   # S = 1024 is the reference's own sampler
     ren = H.Renderer(args.n_images, n_levels=L, n_channels=F, log2_table=args.log2_table,
-                     max_samples=S, step=4.0 / S)
+                     max_samples=S, step=step_len)
     params = ren.named_parameters()
     with torch.no_grad():
         # "trained-like" table: N(0, 0.1^2) exercises the f16 range and real gradients
@@ -216,13 +226,16 @@ def main():
     poses = fox_like_poses(args.n_images).to(dev)
     intr = torch.tensor([[1111.1, 0, args.width / 2], [0, 1111.1, args.height / 2], [0, 0, 1.0]],
                         device=dev)
-    n_rays_view = args.height * args.width
+    n_rays_view = args.rays if args.rays > 0 else args.height * args.width
     total_steps = args.warmup + args.steps
     # inputs resident in HBM before timing: rays + ground truth of every view this rank renders
     views = []
     for s in range(total_steps):
         v = pkg.sharding.view_for(s, rank, world, args.n_images)
         o, d = view_rays(H, poses[v], intr, args.height, args.width)
+        if args.rays > 0:
+            pick = torch.randint(0, o.shape[0], (args.rays,), device=dev)
+            o, d = o[pick].contiguous(), d[pick].contiguous()
         gt = torch.rand(n_rays_view, 3, device=dev)
         emb = torch.full((n_rays_view,), v, dtype=torch.int32, device=dev)
         views.append((o, d, gt, emb))
@@ -297,9 +310,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "ngp_fox-like synthetic views %dx%d, %d samples/ray, L=%d F=%d T=2^%d, "
-                                   "%d-ray chunks, TRAIN render + loss + backward (optimizer excluded)"
-                                   % (args.height, args.width, S, L, F, args.log2_table, args.chunk),
+            "config": {"workload": ("ngp_fox-like synthetic views %dx%d, " % (args.height, args.width) if
+                                    args.rays == 0 else "%d random rays per step, " % args.rays) +
+                                   "%d samples/ray, L=%d F=%d T=2^%d, %d-ray chunks, TRAIN render + "
+                                   "loss + backward (optimizer excluded)"
+                                   % (S, L, F, args.log2_table, args.chunk),
                        "regime": args.regime, "rays_per_step_per_gpu": n_rays_view,
                        "samples_per_ray_kept": n_samples_total / (n_rays_view * args.steps),
                        "sharding": "one view per rank per step, RCCL all-reduce of {sq_err, n} only"},
