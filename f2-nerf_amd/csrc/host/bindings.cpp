@@ -3,6 +3,7 @@
 // call the C ABI of libf2nerf_hip.so.
 #include <torch/extension.h>
 
+#include "fused_adam.hpp"
 #include "hash_3d_anchored.hpp"
 #include "kernel_timer.hpp"
 #include "points_sampler.hpp"
@@ -63,7 +64,7 @@ py::tuple result_tuple(const RenderResult & r)
 
 struct AdamHandle
 {
-  std::shared_ptr<torch::optim::Adam> opt;
+  std::shared_ptr<torch::optim::Optimizer> opt;
 };
 
 }  // namespace
@@ -242,13 +243,22 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         h.opt = std::make_shared<torch::optim::Adam>(r.optim_param_groups(lr));
         return h;
       },
-      "torch::optim::Adam over optim_param_groups(lr) (reference train_manager.cpp:55)");
+      "torch::optim::Adam over optim_param_groups(lr) (reference train_manager.cpp:55)")
+    .def(
+      "make_fused_adam",
+      [](Renderer & r, float lr) {
+        AdamHandle h;
+        h.opt = std::make_shared<FusedAdam>(r.optim_param_groups(lr), r.scene_field_);
+        return h;
+      },
+      "FusedAdam over the same groups: one kernel per parameter, emits the table's f16 shadow");
 
   py::class_<AdamHandle>(m, "Adam")
     .def("step", [](AdamHandle & h) { h.opt->step(); }, py::call_guard<py::gil_scoped_release>())
     .def("zero_grad", [](AdamHandle & h) { h.opt->zero_grad(); })
     .def("n_groups", [](AdamHandle & h) { return h.opt->param_groups().size(); })
     .def("set_lr", [](AdamHandle & h, double lr) {
-      for (auto & g : h.opt->param_groups()) g.options().set_lr(lr);
+      for (auto & g : h.opt->param_groups())
+        static_cast<torch::optim::AdamOptions &>(g.options()).lr(lr);
     });
 }

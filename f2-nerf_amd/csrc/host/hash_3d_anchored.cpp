@@ -130,6 +130,20 @@ Tensor Hash3DAnchored::table_f16()
   return feat_pool_f16_;
 }
 
+Tensor Hash3DAnchored::shadow_storage()
+{
+  if (!feat_pool_f16_.defined() || feat_pool_f16_.numel() != feat_pool_.numel() ||
+      feat_pool_f16_.device() != feat_pool_.device())
+    feat_pool_f16_ = torch::empty(feat_pool_.sizes(), feat_pool_.options().dtype(torch::kFloat16));
+  return feat_pool_f16_;
+}
+
+void Hash3DAnchored::mark_shadow_fresh()
+{
+  shadow_src_ = feat_pool_.data_ptr();
+  shadow_version_ = feat_pool_._version();
+}
+
 Tensor Hash3DAnchored::table_for(const Tensor & feat_pool)
 {
   if (feat_pool.data_ptr() == feat_pool_.data_ptr()) return table_f16();

@@ -56,6 +56,11 @@ public:
   // f16 copy of an arbitrary table tensor (the shadow when it is feat_pool_ itself).
   Tensor table_for(const Tensor & feat_pool);
 
+  // For an optimiser that rewrites the shadow itself while updating feat_pool_ (FusedAdam): the
+  // shadow buffer (allocated on demand), and the call that declares it current.
+  Tensor shadow_storage();
+  void mark_shadow_fresh();
+
   std::vector<torch::optim::OptimizerParamGroup> optim_param_groups(float lr);
 
   Hash3DAnchoredOptions options_;

@@ -235,6 +235,19 @@ int f2n_shade_bwd(
   float * g_w_h, float * g_b_h, float * g_w1, float * g_b1, float * g_w2, float * g_b2,
   float * g_app_emb, int64_t n, void * stream);
 
+/* ------------------------------------------------------------------ optimiser (section 8f) ----- */
+
+/* One fused pass of torch::optim::Adam::step() over one f32 parameter tensor -- the call at
+ * src/main_functions/train_manager.cpp:106 with the options of src/hash_3d_anchored.cpp:90-114
+ * (betas 0.9/0.99, eps 1e-15, weight decay 0 for the table, 1e-6 elsewhere) -- that also writes the
+ * RNE f16 copy of the updated parameter when shadow_f16 != NULL (the feat_pool.to(kFloat16) of
+ * src/hash_3d_anchored.cu:169,198, done once here instead of three times per iteration).
+ * `step` is the 1-based step count (bias corrections 1 - beta^step are formed on the host). */
+int f2n_adam_step(
+  float * param, const float * grad, float * exp_avg, float * exp_avg_sq, uint16_t * shadow_f16,
+  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+  void * stream);
+
 #ifdef __cplusplus
 }
 #endif
