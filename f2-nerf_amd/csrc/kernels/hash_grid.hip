@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kSliceBlock) void hash_bwd_sliced_kernel(
 // levels) is applied with direct global atomics, so results never depend on the capacity.  Versus v2
 // the hash arithmetic runs once instead of once per slice; the price is 2 x 8 bytes of streamed
 // traffic per contribution (F = 2) and a workspace of ~2x that volume.
-constexpr int kBinBlock = 256;
+constexpr int kBinBlock = 1024;
 // LDS float atomics are slow on gfx950: ds_add_f32 / ds_pk_add_f16 sustain ~0.2 T lane-ops/s chip
 // wide, ds_add_u32 / ds_add_u64 ~2.4 T (tools/probes/lds_atomic_rate.hip: 170 vs 14 cycles per wave
 // instruction).  Every contribution is an f16 value, i.e. an integer multiple of 2^-24 below 2^16,
@@ -291,7 +291,7 @@ __device__ __forceinline__ uint32_t record_channel_bits(const uint32_t * rec, in
   return (k & 1) ? (word >> 16) : (word & 0xffffu);
 }
 
-constexpr int kBinQueueWords = 8192;  // 32 KiB of LDS record staging per 256-point tile
+constexpr int kBinQueueWords = 32768;  // 128 KiB of LDS record staging per tile
 
 template <int F, bool POW2>
 __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
@@ -415,14 +415,19 @@ __global__ __launch_bounds__(kSliceBlock) void hash_bwd_reduce_kernel(
     const uint32_t my_cnt = (t0 + lane < n_tiles) ? counts[t0 + lane] : 0u;
     const int n_here = (int)min((int64_t)64, n_tiles - t0);
     for (int j0 = 0; j0 < n_here; j0 += 4) {
-      for (int h = 0; h < n_half; h++) {
+      uint32_t cnt[4];
+      uint32_t cnt_max = 0u;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (j0 + u) & 63);
+        if ((j0 + u) >= n_here) cnt[u] = 0u;
+        cnt_max = max(cnt_max, cnt[u]);
+      }
+      for (int h = 0; h < n_half && (uint32_t)(64 * h) < cnt_max; h++) {  // wave-uniform bound
         uint32_t rec[4][RW];
-        uint32_t cnt[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (j0 + u) & 63);
           const bool live = (j0 + u) < n_here;
-          if (!live) cnt[u] = 0u;
           const uint32_t * region = base + (size_t)(t0 + (live ? j0 + u : 0)) * tile_stride;
           // branch-free load so the four loads are in flight together: lanes past the region's
           // count re-read its last record (same cache lines, no extra traffic) and skip it below
@@ -656,7 +661,7 @@ BinPlan bin_plan(int64_t n, int L, int F, uint32_t T, int64_t workspace_bytes)
   const int64_t n_tiles = (n + kBinBlock - 1) / kBinBlock;
   const int avg = (8 * kBinBlock + (int)n_slices - 1) / (int)n_slices;  // records per region
   // two 64-lane loads per region in the reduce kernel, and the tile's queues must fit the LDS stage
-  int qcap = std::min({128, 2 * avg, kBinQueueWords / ((int)n_slices * rw)});
+  int qcap = std::min(2 * avg, kBinQueueWords / ((int)n_slices * rw));
   if (qcap < avg + avg / 4) return pl;
   pl.counts_bytes = ((int64_t)L * n_slices * n_tiles * 4 + 255) / 256 * 256;
   if (workspace_bytes > 0) {
@@ -665,7 +670,6 @@ BinPlan bin_plan(int64_t n, int L, int F, uint32_t T, int64_t workspace_bytes)
     if (fit < avg / 2) return pl;  // too small to be worth it
     qcap = (int)std::min<int64_t>(qcap, fit);
   }
-  if (avg > 128) return pl;  // few slices: a region could not hold even the average tile
   pl.n_slices = (int)n_slices;
   pl.qcap = qcap;
   pl.n_tiles = n_tiles;
