@@ -118,12 +118,24 @@ __global__ __launch_bounds__(F2N_BLOCK) void shade_fwd_kernel(
 //   5. d_enc = w_h^T d_h (rolled over the 16 head outputs), d w_h, biases, embedding
 // The [64][65] tile is read conflict-free both ways: element (s, j) sits at j*65 + s.
 
-constexpr int kBwdWaves = 4;            // waves per workgroup
 constexpr int kTP = 65;                 // row pitch of the [neuron][sample] tile
-constexpr int kTileP = 64 * (kHid + 4);  // 17 KiB: holds [64][65] and, in step 5b, [64 samples][C+4]
-constexpr int kXP = kIn2 + 4;           // row pitch of the [sample][32] tile (float4 rows)
-constexpr int kTileX = 64 * kXP;        //  9 KiB
-constexpr int kWavelds = kTileP + kTileX;
+constexpr int kDoOff = kHid * kTP;      // [64 samples][3] d_o rows live in the tile's tail
+constexpr int kHP = kOut1 + 4;          // row pitch of the [sample][16] rows of step 5b
+
+// Per-wave LDS tile.  Occupancy is what this kernel lives on: with one wave per SIMD every LDS read
+// stalls the SIMD (4.4 ms per 8.4 M samples); a second wave hides it.  The tile is therefore the only
+// per-wave LDS object (17 KiB at C <= 32: eight waves + the weights = 151 KiB), and the broadcast of
+// X[s][:] in step 4 uses v_readlane instead of a second tile.
+template <int C>
+struct BwdShape
+{
+  static constexpr int kERowP = C + 4;                 // [sample][C] rows of step 5b
+  static constexpr int kHOff = 64 * kERowP;            // then [sample][16+4] rows
+  static constexpr int kTile =
+    (kHOff + 64 * kHP > kDoOff + 64 * 3) ? kHOff + 64 * kHP : kDoOff + 64 * 3;
+  static constexpr int kWeights = kOut1 * (C + 4) + kHid * (kIn2 + 4) + kHid * 4 + 4;
+  static constexpr int kWaves = ((kWeights + 8 * kTile) * 4 <= 160 * 1024) ? 8 : 4;
+};
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -135,7 +147,7 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 template <int C>
-__global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
+__global__ __launch_bounds__(BwdShape<C>::kWaves * 64) void shade_bwd_kernel(
   const float * __restrict__ enc, const float * __restrict__ dirs,
   const int32_t * __restrict__ sample_img, const float * __restrict__ p_w_h,
   const float * __restrict__ p_b_h, const float * __restrict__ p_w1,
@@ -147,12 +159,18 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
   float * __restrict__ g_emb, int64_t n)
 {
   static_assert(C % 4 == 0 && C <= kHid, "C must be a multiple of 4 and at most 64");
+  constexpr int kBwdWaves = BwdShape<C>::kWaves;
+  constexpr int kWavelds = BwdShape<C>::kTile;
   // weights, staged once per workgroup: rows padded by 4 floats with the bias in the first pad slot
   constexpr int kWhP = C + 4, kW1P = kIn2 + 4;
   constexpr int kOffWh = 0, kOffW1 = kOffWh + kOut1 * kWhP, kOffW2T = kOffW1 + kHid * kW1P,
                 kOffB2 = kOffW2T + kHid * 4, kWTotal = kOffB2 + 4;
-  __shared__ __attribute__((aligned(16))) float lds_w[kWTotal];
-  __shared__ __attribute__((aligned(16))) float lds[kBwdWaves * kWavelds];
+  // one LDS object, weights first: their byte offsets stay below 64 KiB, the range of the DS
+  // instructions' immediate offset field (a second __shared__ array landed above 0x1a000 and every
+  // weight address needed its own v_add)
+  __shared__ __attribute__((aligned(16))) float lds_all[kWTotal + kBwdWaves * kWavelds];
+  float * lds_w = lds_all;
+  float * lds = lds_all + kWTotal;
   for (int i = threadIdx.x; i < kOut1 * C; i += kBwdWaves * 64)
     lds_w[kOffWh + (i / C) * kWhP + (i % C)] = p_w_h[i];
   for (int i = threadIdx.x; i < kHid * kIn2; i += kBwdWaves * 64)
@@ -169,8 +187,13 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
 
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
+  // A zero that lives in a VGPR and that the compiler cannot see through.  Added to the (wave-uniform)
+  // neuron index it makes the weight-row address VGPR-based, so the eight ds_read_b128 of a row use
+  // ONE address register + immediate offsets; with a scalar base hipcc rebuilt every address with
+  // s_add + v_mov (41 of the 145 instructions of a two-neuron iteration).
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
   float * tileP = lds + wave * kWavelds;  // [64 neurons][65]: pre-activations, then d_hid
-  float * tileX = tileP + kTileP;         // [64 samples][36] rows, reused for small per-sample vectors
   const bool has_emb = (p_emb != nullptr) && (sample_img != nullptr);
 
   // per-lane accumulators that live across all strides of this wave
@@ -205,10 +228,10 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
     const int img = has_emb ? sample_img[pc] : 0;
     float X[kIn2];
     {
-      // field head: h[i] -> column i of tileX viewed as [16][64]
+      // field head: h[i] -> column i of the (still unused) tile viewed as [16][64]
 #pragma unroll 2
       for (int i = 0; i < kOut1; i++) {
-        const float * row = lds_w + kOffWh + i * kWhP;
+        const float * row = lds_w + kOffWh + (i + vzero) * kWhP;
         float acc = row[C];
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
@@ -218,11 +241,11 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
           acc = fmaf(e[c + 2], w.z, acc);
           acc = fmaf(e[c + 3], w.w, acc);
         }
-        tileX[i * 64 + lane] = acc;
+        tileP[i * 64 + lane] = acc;
       }
       X[0] = 1.f;
 #pragma unroll
-      for (int i = 1; i < kOut1; i++) X[i] = tileX[i * 64 + lane];
+      for (int i = 1; i < kOut1; i++) X[i] = tileP[i * 64 + lane];
       if (has_emb) {
         const float * emb_row = p_emb + (int64_t)img * kOut1;
 #pragma unroll
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
       o[2] = b2.z;
 #pragma unroll 2
       for (int j = 0; j < kHid; j++) {
-        const float * row = lds_w + kOffW1 + j * kW1P;
+        const float * row = lds_w + kOffW1 + (j + vzero) * kW1P;
         float acc = row[kIn2];
 #pragma unroll
         for (int i = 0; i < kIn2; i += 4) {
@@ -250,7 +273,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
         }
         tileP[j * kTP + lane] = acc;  // pre-activation
         const float hj = fmaxf(acc, 0.f);
-        const float4 w2 = *reinterpret_cast<const float4 *>(lds_w + kOffW2T + j * 4);
+        const float4 w2 = *reinterpret_cast<const float4 *>(lds_w + kOffW2T + (j + vzero) * 4);
         o[0] = fmaf(hj, w2.x, o[0]);
         o[1] = fmaf(hj, w2.y, o[1]);
         o[2] = fmaf(hj, w2.z, o[2]);
@@ -267,15 +290,17 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
     }
 
     // ---- 2. d w2[c][j] += sum_s d_o[s][c] * relu(pre[s][j])     (lane = j)
-    *reinterpret_cast<float4 *>(tileX + lane * 4) = make_float4(d_o[0], d_o[1], d_o[2], 0.f);
+    tileP[kDoOff + lane * 3 + 0] = d_o[0];
+    tileP[kDoOff + lane * 3 + 1] = d_o[1];
+    tileP[kDoOff + lane * 3 + 2] = d_o[2];
     wave_lds_sync();
 #pragma unroll 4
     for (int s = 0; s < 64; s++) {
       const float a = fmaxf(tileP[lane * kTP + s], 0.f);
-      const float4 g = *reinterpret_cast<const float4 *>(tileX + s * 4);
-      acc_w2[0] = fmaf(g.x, a, acc_w2[0]);
-      acc_w2[1] = fmaf(g.y, a, acc_w2[1]);
-      acc_w2[2] = fmaf(g.z, a, acc_w2[2]);
+      const float * g = tileP + kDoOff + (s + vzero) * 3;
+      acc_w2[0] = fmaf(g[0], a, acc_w2[0]);
+      acc_w2[1] = fmaf(g[1], a, acc_w2[1]);
+      acc_w2[2] = fmaf(g[2], a, acc_w2[2]);
     }
     wave_lds_sync();
 
@@ -286,13 +311,13 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
 #pragma unroll 2
     for (int j = 0; j < kHid; j++) {
       const float pre = tileP[j * kTP + lane];
-      const float4 w2 = *reinterpret_cast<const float4 *>(lds_w + kOffW2T + j * 4);
+      const float4 w2 = *reinterpret_cast<const float4 *>(lds_w + kOffW2T + (j + vzero) * 4);
       float dh = d_o[0] * w2.x;
       dh = fmaf(d_o[1], w2.y, dh);
       dh = fmaf(d_o[2], w2.z, dh);
       dh = (pre > 0.f) ? dh : 0.f;
       tileP[j * kTP + lane] = dh;
-      const float * row = lds_w + kOffW1 + j * kW1P;
+      const float * row = lds_w + kOffW1 + (j + vzero) * kW1P;
 #pragma unroll
       for (int i = 0; i < kOut1; i += 4) {  // only the 16 non-SH input columns carry gradient
         const float4 w = *reinterpret_cast<const float4 *>(row + i);
@@ -311,22 +336,17 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
     for (int i = 0; i < kOut1; i++) acc_bh[i] += d_h[i];
 
     // ---- 4. d w1[j][i] += sum_s d_hid[s][j] * X[s][i] ; d b1[j] += sum_s d_hid[s][j]   (lane = j)
-#pragma unroll
-    for (int i = 0; i < kIn2; i += 4)
-      *reinterpret_cast<float4 *>(tileX + lane * kXP + i) =
-        make_float4(X[i], X[i + 1], X[i + 2], X[i + 3]);
+    // X[s][:] is wave-uniform per s: v_readlane broadcasts it from lane s's registers into SGPRs
     wave_lds_sync();
 #pragma unroll 2
     for (int s = 0; s < 64; s++) {
       const float a = tileP[lane * kTP + s];
       acc_b1 += a;
 #pragma unroll
-      for (int i = 0; i < kIn2; i += 4) {
-        const float4 x = *reinterpret_cast<const float4 *>(tileX + s * kXP + i);
-        acc_w1[i] = fmaf(a, x.x, acc_w1[i]);
-        acc_w1[i + 1] = fmaf(a, x.y, acc_w1[i + 1]);
-        acc_w1[i + 2] = fmaf(a, x.z, acc_w1[i + 2]);
-        acc_w1[i + 3] = fmaf(a, x.w, acc_w1[i + 3]);
+      for (int i = 0; i < kIn2; i++) {
+        const float xs =
+          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(X[i]), s));
+        acc_w1[i] = fmaf(a, xs, acc_w1[i]);
       }
     }
     wave_lds_sync();
@@ -342,7 +362,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
 #pragma unroll 2
       for (int i = 0; i < kOut1; i++) {
         const float a = tileP[i * 64 + lane];
-        const float * row = lds_w + kOffWh + i * kWhP;
+        const float * row = lds_w + kOffWh + (i + vzero) * kWhP;
 #pragma unroll
         for (int c = 0; c < C; c += 4) {
           const float4 w = *reinterpret_cast<const float4 *>(row + c);
@@ -360,27 +380,27 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
 
     // ---- 5b. d w_h[i][c] += sum_s d_h[s][i] * enc[s][c]
     {
-      constexpr int kEP = C + 4;       // [sample][C] rows in tileP (C <= 64)
-      constexpr int kHP = kOut1 + 4;   // [sample][16] rows in tileX
+      constexpr int kEP = BwdShape<C>::kERowP;  // [sample][C] rows at the start of the tile
+      float * rowsH = tileP + BwdShape<C>::kHOff;  // [sample][16+4] rows behind them
       wave_lds_sync();
 #pragma unroll
       for (int c = 0; c < C; c += 4)
         *reinterpret_cast<float4 *>(tileP + lane * kEP + c) =
           make_float4(e[c], e[c + 1], e[c + 2], e[c + 3]);
       // row of {dX[0] (embedding only), d_h[1..15]} plus d_h[0] in the pad slot
-      *reinterpret_cast<float4 *>(tileX + lane * kHP) =
+      *reinterpret_cast<float4 *>(rowsH + lane * kHP) =
         make_float4(valid ? dX[0] : 0.f, d_h[1], d_h[2], d_h[3]);
 #pragma unroll
       for (int i = 4; i < kOut1; i += 4)
-        *reinterpret_cast<float4 *>(tileX + lane * kHP + i) =
+        *reinterpret_cast<float4 *>(rowsH + lane * kHP + i) =
           make_float4(d_h[i], d_h[i + 1], d_h[i + 2], d_h[i + 3]);
-      tileX[lane * kHP + kOut1] = d_h[0];
+      rowsH[lane * kHP + kOut1] = d_h[0];
       wave_lds_sync();
       const int wi = lane & 15, wq = lane >> 4;
       const int col = (wi == 0) ? kOut1 : wi;  // head output 0's gradient lives in the pad slot
 #pragma unroll 4
       for (int s = 0; s < 64; s++) {
-        const float a = tileX[s * kHP + col];
+        const float a = rowsH[s * kHP + col];
 #pragma unroll
         for (int k = 0; k < CQ; k += 4) {
           const float4 x = *reinterpret_cast<const float4 *>(tileP + s * kEP + wq * CQ + k);
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(kBwdWaves * 64) void shade_bwd_kernel(
           // lane (i = lane&15, part = lane>>4) sums 16 of the 64 samples, then the 4 parts combine
           float part = 0.f;
 #pragma unroll
-          for (int s = 0; s < 16; s++) part += tileX[(wq * 16 + s) * kHP + wi];
+          for (int s = 0; s < 16; s++) part += rowsH[(wq * 16 + s) * kHP + wi];
           part += __shfl_xor(part, 16);
           part += __shfl_xor(part, 32);
           if (lane < 16) atomicAdd(g_emb + (int64_t)img0 * kOut1 + lane, part);
@@ -476,10 +496,11 @@ extern "C" int f2n_shade_bwd(
     return F2N_E_INVALID_ARG;
   if (app_emb && sample_img && !g_app_emb) return F2N_E_INVALID_ARG;
   const int64_t n_strides = (n + 63) / 64;
-  // persistent waves: one workgroup per CU is all the LDS allows (4 x 26 KiB); fewer if n is small
-  const unsigned grid = (unsigned)std::min<int64_t>(256, (n_strides + kBwdWaves - 1) / kBwdWaves);
-  F2N_DISPATCH_C(C, hipLaunchKernelGGL(
-                      (shade_bwd_kernel<CC>), dim3(grid), dim3(kBwdWaves * 64), 0,
+  // persistent waves: one workgroup per CU (its LDS holds the weights + 8 wave tiles); fewer if n is small
+  F2N_DISPATCH_C(C, constexpr int kW = BwdShape<CC>::kWaves;
+                    const unsigned grid = (unsigned)std::min<int64_t>(256, (n_strides + kW - 1) / kW);
+                    hipLaunchKernelGGL(
+                      (shade_bwd_kernel<CC>), dim3(grid), dim3(kW * 64), 0,
                       (hipStream_t)stream, enc_cm, dirs, sample_img, w_h, b_h, w1, b1, w2, b2,
                       app_emb, d_logit, d_rgb, d_enc_cm,
                       g_w_h, g_b_h, g_w1, g_b1, g_w2, g_b2, g_app_emb, n))
