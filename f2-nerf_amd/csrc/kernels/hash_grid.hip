@@ -299,33 +299,49 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
   const float * __restrict__ bias, const float * __restrict__ mul,
   const float * __restrict__ grad_out, int64_t g_ld_point, int64_t g_ld_chan,
   float * __restrict__ table_grad, uint32_t * __restrict__ ws_records,
-  uint32_t * __restrict__ ws_counts, int64_t n, uint32_t T, int64_t level_stride, float grad_scale,
-  float inv_scale, int n_slices, int qcap, int64_t n_tiles)
+  uint32_t * __restrict__ ws_counts, int64_t n, int L, uint32_t T, int64_t level_stride,
+  float grad_scale, float inv_scale, int n_slices, int qcap, int64_t n_tiles)
 {
   constexpr int RW = BinRecord<F>::kWords;
   constexpr uint32_t kRows = kBinAcc / F;
-  // records are staged per slice in LDS and leave as whole contiguous regions (one 512-byte wave
-  // store per region at the reference size) instead of 64 scattered 8-byte stores per instruction
+  // records are staged per slice in LDS and leave as whole contiguous regions instead of 64
+  // scattered 8-byte stores per instruction
   __shared__ uint32_t queue[kBinQueueWords];
   __shared__ uint32_t qcount[64];
-  const int l = blockIdx.y;
+  // One workgroup owns a tile of points for ALL levels: the point is read once, and the gradient
+  // channels of level l+1 are requested before level l is processed -- with a 128 KiB LDS stage only
+  // one workgroup fits a CU, so nothing else would hide that load.
   const int64_t tile = blockIdx.x;
   const int64_t p = tile * kBinBlock + threadIdx.x;
-  if (threadIdx.x < 64) qcount[threadIdx.x] = 0u;
-  __syncthreads();
+  const bool valid = p < n;
+  const int64_t pc = valid ? p : n - 1;
+  const float x = pts[3 * pc + 0], y = pts[3 * pc + 1], z = pts[3 * pc + 2];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
 
-  if (p < n) {
-    const LevelParams lp = load_level(primes, bias, mul, l);
-    const float x = pts[3 * p + 0], y = pts[3 * p + 1], z = pts[3 * p + 2];
-    const float * g = grad_out + p * g_ld_point + (int64_t)(l * F) * g_ld_chan;
+  float g_cur[F], g_nxt[F];
+#pragma unroll
+  for (int k = 0; k < F; k++) g_cur[k] = grad_out[pc * g_ld_point + (int64_t)k * g_ld_chan];
+
+  for (int l = 0; l < L; l++) {
+    if (threadIdx.x < 64) qcount[threadIdx.x] = 0u;
+    {
+      const int ln = (l + 1 < L) ? l + 1 : l;  // clamped: the last prefetch re-reads level L-1
+#pragma unroll
+      for (int k = 0; k < F; k++)
+        g_nxt[k] = grad_out[pc * g_ld_point + (int64_t)(ln * F + k) * g_ld_chan];
+    }
+    __syncthreads();
+
     float gk[F];
     bool any = false;
 #pragma unroll
     for (int k = 0; k < F; k++) {
-      gk[k] = round_f16(g[k * g_ld_chan] * grad_scale);
+      gk[k] = round_f16(g_cur[k] * grad_scale);
       any |= (gk[k] != 0.f);
     }
-    if (any) {
+    if (valid && any) {
+      const LevelParams lp = load_level(primes, bias, mul, l);
       uint32_t row[8];
       float w[8];
       corner_rows_and_weights<POW2>(x, y, z, lp, T, row, w);
@@ -367,26 +383,27 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
         }
       }
     }
-  }
-  __syncthreads();
-  // flush: wave w copies the queues of slices w, w+4, ... to their workspace regions
-  const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
-  uint32_t * region0 = ws_records + ((size_t)l * n_tiles + tile) * n_slices * (size_t)qcap * RW;
-  for (int sidx = wave; sidx < n_slices; sidx += kBinBlock / 64) {
-    const uint32_t cnt = min(qcount[sidx], (uint32_t)qcap);
-    const uint32_t * q = queue + (size_t)sidx * qcap * RW;
-    uint32_t * dst = region0 + (size_t)sidx * qcap * RW;
-    if constexpr (RW == 2) {
-      for (uint32_t i = lane; i < cnt; i += 64)
-        reinterpret_cast<uint2 *>(dst)[i] = reinterpret_cast<const uint2 *>(q)[i];
-    } else {
-      for (uint32_t i = lane; i < cnt * RW; i += 64) dst[i] = q[i];
+    __syncthreads();
+    // flush: wave w copies the queues of slices w, w+16, ... to their workspace regions
+    uint32_t * region0 = ws_records + ((size_t)l * n_tiles + tile) * n_slices * (size_t)qcap * RW;
+    for (int sidx = wave; sidx < n_slices; sidx += kBinBlock / 64) {
+      const uint32_t cnt = min(qcount[sidx], (uint32_t)qcap);
+      const uint32_t * q = queue + (size_t)sidx * qcap * RW;
+      uint32_t * dst = region0 + (size_t)sidx * qcap * RW;
+      if constexpr (RW == 2) {
+        for (uint32_t i = lane; i < cnt; i += 64)
+          reinterpret_cast<uint2 *>(dst)[i] = reinterpret_cast<const uint2 *>(q)[i];
+      } else {
+        for (uint32_t i = lane; i < cnt * RW; i += 64) dst[i] = q[i];
+      }
     }
+    if ((int)threadIdx.x < n_slices)
+      ws_counts[((size_t)l * n_slices + threadIdx.x) * n_tiles + tile] =
+        min(qcount[threadIdx.x], (uint32_t)qcap);
+    __syncthreads();  // queues and counters are reused by the next level
+#pragma unroll
+    for (int k = 0; k < F; k++) g_cur[k] = g_nxt[k];
   }
-  if ((int)threadIdx.x < n_slices)
-    ws_counts[((size_t)l * n_slices + threadIdx.x) * n_tiles + tile] =
-      min(qcount[threadIdx.x], (uint32_t)qcap);
 }
 
 template <int F>
@@ -705,12 +722,12 @@ extern "C" int f2n_hash_bwd_binned(
   uint32_t * records = reinterpret_cast<uint32_t *>((char *)workspace + pl.counts_bytes);
   const bool p2 = is_pow2(T);
   const float inv = 1.f / grad_scale;
-  const dim3 grid1((unsigned)pl.n_tiles, (unsigned)L), block1(kBinBlock);
+  const dim3 grid1((unsigned)pl.n_tiles), block1(kBinBlock);
   const dim3 grid2((unsigned)pl.n_slices, (unsigned)L), block2(kSliceBlock);
 #define F2N_BIN(P2)                                                                               \
   hipLaunchKernelGGL(                                                                             \
     (hash_bwd_bin_kernel<FF, P2>), grid1, block1, 0, s, pts, primes, bias, mul, grad_out,         \
-    g_ld_point, g_ld_chan, table_grad, records, counts, n, T, level_stride, grad_scale, inv,      \
+    g_ld_point, g_ld_chan, table_grad, records, counts, n, L, T, level_stride, grad_scale, inv,   \
     pl.n_slices, pl.qcap, pl.n_tiles)
   F2N_DISPATCH_F(F, {
     if (p2) F2N_BIN(true);
