@@ -20,6 +20,10 @@
 //
 // Activations enc / d_enc are channel-major [C, n] (the layout f2n_hash_fwd / f2n_hash_bwd use).
 #include "sh_basis.hiph"
+#include "shade_mfma.hiph"
+
+#include <cstdlib>
+#include <cstring>
 
 namespace
 {
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(F2N_BLOCK) void shade_fwd_kernel(
   const float * __restrict__ p_b_h, const float * __restrict__ p_w1,
   const float * __restrict__ p_b1, const float * __restrict__ p_w2,
   const float * __restrict__ p_b2, const float * __restrict__ p_emb, float * __restrict__ logit,
-  float * __restrict__ rgb, int64_t n)
+  float * __restrict__ rgb, float * __restrict__ pre_out, int64_t n)
 {
   const int64_t p = (int64_t)blockIdx.x * F2N_BLOCK + threadIdx.x;
   if (p >= n) return;
@@ -100,6 +104,12 @@ __global__ __launch_bounds__(F2N_BLOCK) void shade_fwd_kernel(
 #pragma unroll
   for (int c = 0; c < 3; c++)
     rgb[3 * p + c] = (1.f + 2.f * kEps) / (1.f + expf(-o[c])) - kEps;
+  // optional: hidden pre-activations, channel-major [64, n], so the backward need not recompute the
+  // 64x32 layer at its low occupancy (coalesced 256-byte stores per wave and neuron)
+  if (pre_out) {
+#pragma unroll
+    for (int j = 0; j < kHid; j++) pre_out[(int64_t)j * n + p] = pre[j];
+  }
 }
 
 // ---- backward -----------------------------------------------------------------------------------
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(BwdShape<C>::kWaves * 64) void shade_bwd_kernel(
   const float * __restrict__ d_logit, const float * __restrict__ d_rgb, float * __restrict__ d_enc,
   float * __restrict__ g_w_h, float * __restrict__ g_b_h, float * __restrict__ g_w1,
   float * __restrict__ g_b1, float * __restrict__ g_w2, float * __restrict__ g_b2,
-  float * __restrict__ g_emb, int64_t n)
+  float * __restrict__ g_emb, const float * __restrict__ pre_in, int64_t n)
 {
   static_assert(C % 4 == 0 && C <= kHid, "C must be a multiple of 4 and at most 64");
   constexpr int kBwdWaves = BwdShape<C>::kWaves;
@@ -259,24 +269,38 @@ __global__ __launch_bounds__(BwdShape<C>::kWaves * 64) void shade_bwd_kernel(
       o[0] = b2.x;
       o[1] = b2.y;
       o[2] = b2.z;
-#pragma unroll 2
-      for (int j = 0; j < kHid; j++) {
-        const float * row = lds_w + kOffW1 + (j + vzero) * kW1P;
-        float acc = row[kIn2];
-#pragma unroll
-        for (int i = 0; i < kIn2; i += 4) {
-          const float4 w = *reinterpret_cast<const float4 *>(row + i);
-          acc = fmaf(X[i], w.x, acc);
-          acc = fmaf(X[i + 1], w.y, acc);
-          acc = fmaf(X[i + 2], w.z, acc);
-          acc = fmaf(X[i + 3], w.w, acc);
+      if (pre_in) {
+        // pre-activations saved by the forward kernel: 64 coalesced loads instead of 2 K FMAs
+#pragma unroll 8
+        for (int j = 0; j < kHid; j++) {
+          const float acc = pre_in[(int64_t)j * n + pc];
+          tileP[j * kTP + lane] = acc;
+          const float hj = fmaxf(acc, 0.f);
+          const float4 w2 = *reinterpret_cast<const float4 *>(lds_w + kOffW2T + (j + vzero) * 4);
+          o[0] = fmaf(hj, w2.x, o[0]);
+          o[1] = fmaf(hj, w2.y, o[1]);
+          o[2] = fmaf(hj, w2.z, o[2]);
         }
-        tileP[j * kTP + lane] = acc;  // pre-activation
-        const float hj = fmaxf(acc, 0.f);
-        const float4 w2 = *reinterpret_cast<const float4 *>(lds_w + kOffW2T + (j + vzero) * 4);
-        o[0] = fmaf(hj, w2.x, o[0]);
-        o[1] = fmaf(hj, w2.y, o[1]);
-        o[2] = fmaf(hj, w2.z, o[2]);
+      } else {
+#pragma unroll 2
+        for (int j = 0; j < kHid; j++) {
+          const float * row = lds_w + kOffW1 + (j + vzero) * kW1P;
+          float acc = row[kIn2];
+#pragma unroll
+          for (int i = 0; i < kIn2; i += 4) {
+            const float4 w = *reinterpret_cast<const float4 *>(row + i);
+            acc = fmaf(X[i], w.x, acc);
+            acc = fmaf(X[i + 1], w.y, acc);
+            acc = fmaf(X[i + 2], w.z, acc);
+            acc = fmaf(X[i + 3], w.w, acc);
+          }
+          tileP[j * kTP + lane] = acc;  // pre-activation
+          const float hj = fmaxf(acc, 0.f);
+          const float4 w2 = *reinterpret_cast<const float4 *>(lds_w + kOffW2T + (j + vzero) * 4);
+          o[0] = fmaf(hj, w2.x, o[0]);
+          o[1] = fmaf(hj, w2.y, o[1]);
+          o[2] = fmaf(hj, w2.z, o[2]);
+        }
       }
     }
 
@@ -467,7 +491,7 @@ __global__ __launch_bounds__(BwdShape<C>::kWaves * 64) void shade_bwd_kernel(
 extern "C" int f2n_shade_fwd(
   const float * enc_cm, int C, const float * dirs, const int32_t * sample_img, const float * w_h,
   const float * b_h, const float * w1, const float * b1, const float * w2, const float * b2,
-  const float * app_emb, float * logit, float * rgb, int64_t n, void * stream)
+  const float * app_emb, float * logit, float * rgb, float * pre_cm, int64_t n, void * stream)
 {
   if (n < 0) return F2N_E_INVALID_ARG;
   if (C != 8 && C != 16 && C != 32 && C != 64) return F2N_E_UNSUPPORTED;
@@ -477,7 +501,7 @@ extern "C" int f2n_shade_fwd(
   const dim3 grid(f2n_div_up(n, F2N_BLOCK)), block(F2N_BLOCK);
   F2N_DISPATCH_C(C, hipLaunchKernelGGL(
                       (shade_fwd_kernel<CC>), grid, block, 0, (hipStream_t)stream, enc_cm, dirs,
-                      sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, logit, rgb, n))
+                      sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, logit, rgb, pre_cm, n))
   return f2n_launch_status();
 }
 
@@ -486,7 +510,7 @@ extern "C" int f2n_shade_bwd(
   const float * b_h, const float * w1, const float * b1, const float * w2, const float * b2,
   const float * app_emb, const float * d_logit, const float * d_rgb, float * d_enc_cm,
   float * g_w_h, float * g_b_h, float * g_w1, float * g_b1, float * g_w2, float * g_b2,
-  float * g_app_emb, int64_t n, void * stream)
+  float * g_app_emb, const float * pre_cm, int64_t n, void * stream)
 {
   if (n < 0) return F2N_E_INVALID_ARG;
   if (C != 8 && C != 16 && C != 32 && C != 64) return F2N_E_UNSUPPORTED;
@@ -495,6 +519,14 @@ extern "C" int f2n_shade_bwd(
       !d_enc_cm || !g_w_h || !g_b_h || !g_w1 || !g_b1 || !g_w2 || !g_b2)
     return F2N_E_INVALID_ARG;
   if (app_emb && sample_img && !g_app_emb) return F2N_E_INVALID_ARG;
+  // matrix-core kernel (shade_mfma.hip) unless the saved pre-activations are offered, the width has
+  // no MFMA tiling, or F2N_SHADE_BWD=valu asks for the vector kernel (A/B measurements)
+  const char * route = std::getenv("F2N_SHADE_BWD");
+  const bool force_valu = route && std::strcmp(route, "valu") == 0;
+  if (!force_valu && !pre_cm && f2n_detail::shade_bwd_mfma_supports(C, n))
+    return f2n_detail::launch_shade_bwd_mfma(
+      enc_cm, C, dirs, sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, d_logit, d_rgb, d_enc_cm,
+      g_w_h, g_b_h, g_w1, g_b1, g_w2, g_b2, g_app_emb, n, (hipStream_t)stream);
   const int64_t n_strides = (n + 63) / 64;
   // persistent waves: one workgroup per CU (its LDS holds the weights + 8 wave tiles); fewer if n is small
   F2N_DISPATCH_C(C, constexpr int kW = BwdShape<CC>::kWaves;
@@ -503,6 +535,6 @@ extern "C" int f2n_shade_bwd(
                       (shade_bwd_kernel<CC>), dim3(grid), dim3(kW * 64), 0,
                       (hipStream_t)stream, enc_cm, dirs, sample_img, w_h, b_h, w1, b1, w2, b2,
                       app_emb, d_logit, d_rgb, d_enc_cm,
-                      g_w_h, g_b_h, g_w1, g_b1, g_w2, g_b2, g_app_emb, n))
+                      g_w_h, g_b_h, g_w1, g_b1, g_w2, g_b2, g_app_emb, pre_cm, n))
   return f2n_launch_status();
 }

@@ -218,22 +218,25 @@ int f2n_composite_bwd(
  * i.e. the three nn::Linear GEMMs, torch::cat x2, ScatterAdd (src/CustomOps/Scatter.cu:11-19),
  * SHKernel (src/sh_shader.cu:11-103) and the element-wise tail.  enc_cm / d_enc_cm are
  * channel-major [C, n] (C = L*F in {8,16,32,64}); w_h [16,C], w1 [64,32], w2 [3,64] row-major as
- * nn::Linear stores them; sample_img [n] image id per sample or NULL (no appearance embedding). */
+ * nn::Linear stores them; sample_img [n] image id per sample or NULL (no appearance embedding).
+ * pre_cm: optional [64, n] output of the hidden layer's pre-activations (what autograd would have
+ * saved for the ReLU); give it to f2n_shade_bwd and that kernel loads them instead of recomputing. */
 int f2n_shade_fwd(
   const float * enc_cm, int C, const float * dirs, const int32_t * sample_img, const float * w_h,
   const float * b_h, const float * w1, const float * b1, const float * w2, const float * b2,
-  const float * app_emb, float * logit, float * rgb, int64_t n, void * stream);
+  const float * app_emb, float * logit, float * rgb, float * pre_cm, int64_t n, void * stream);
 
 /* Backward of the above (recomputes the forward per sample).  d_enc_cm is overwritten; the seven
  * parameter gradients are ACCUMULATED INTO (caller zeroes them); g_app_emb may be NULL when
- * app_emb / sample_img are.  Replaces the autograd chain of the ops listed above, including
+ * app_emb / sample_img are; pre_cm = the forward's optional output or NULL (recompute).  Replaces the
+ * autograd chain of the ops listed above, including
  * ScatterAddFuncBackwardBlock -- src/CustomOps/Scatter.cu:21-41,72-101. */
 int f2n_shade_bwd(
   const float * enc_cm, int C, const float * dirs, const int32_t * sample_img, const float * w_h,
   const float * b_h, const float * w1, const float * b1, const float * w2, const float * b2,
   const float * app_emb, const float * d_logit, const float * d_rgb, float * d_enc_cm,
   float * g_w_h, float * g_b_h, float * g_w1, float * g_b1, float * g_w2, float * g_b2,
-  float * g_app_emb, int64_t n, void * stream);
+  float * g_app_emb, const float * pre_cm, int64_t n, void * stream);
 
 /* ------------------------------------------------------------------ optimiser (section 8f) ----- */
 

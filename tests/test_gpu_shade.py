@@ -27,8 +27,9 @@ def _reference(enc, dirs, img, P, d_logit, d_rgb):
 
 
 @pytest.mark.parametrize("C,n,with_emb", [(32, 5000, True), (32, 64 * 9 + 17, False), (8, 3000, True),
-                                          (64, 2000, True), (16, 1, True)])
-def test_shade_fwd_bwd(capi, dev, C, n, with_emb):
+                                          (64, 2000, True), (16, 1, True), (16, 777, False),
+                                          (32, 64 * 2100 + 5, True)])
+def test_shade_fwd_bwd(capi, dev, monkeypatch, C, n, with_emb):
     g = torch.Generator().manual_seed(C + n)
     E = 5
     enc = (torch.randn(n, C, generator=g) * 0.1).to(torch.float16).float()
@@ -51,24 +52,35 @@ def test_shade_fwd_bwd(capi, dev, C, n, with_emb):
     emb = Pd["emb"] if with_emb else None
     logit = torch.empty(n, device=dev)
     rgb = torch.empty(n, 3, device=dev)
+    pre_cm = torch.empty(64, n, device=dev)
     capi.call("shade_fwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
-              Pd["w2"], Pd["b2"], emb, logit, rgb, n)
+              Pd["w2"], Pd["b2"], emb, logit, rgb, pre_cm, n)
     torch.testing.assert_close(logit.cpu(), r_logit, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rgb.cpu(), r_rgb, rtol=1e-4, atol=1e-5)
 
-    d_enc = torch.full((C, n), 7.0, device=dev)      # must be overwritten
-    G = {k: torch.zeros_like(v) for k, v in Pd.items()}
-    capi.call("shade_bwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
-              Pd["w2"], Pd["b2"], emb, dv(d_logit), dv(d_rgb), d_enc, G["w_h"], G["b_h"], G["w1"],
-              G["b1"], G["w2"], G["b2"], G["emb"] if with_emb else None, n)
-    torch.testing.assert_close(d_enc.t().cpu(), r_denc, rtol=1e-3, atol=1e-4 * float(r_denc.abs().max()))
-    for k in ("w_h", "b_h", "w1", "b1", "w2", "b2") + (("emb",) if with_emb else ()):
-        ref = r_g[k]
-        torch.testing.assert_close(G[k].cpu(), ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max()),
-                                   msg=lambda m, k=k: k + ": " + m)
-    # accumulate semantics of the parameter gradients
-    capi.call("shade_bwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
-              Pd["w2"], Pd["b2"], emb, dv(d_logit), dv(d_rgb), d_enc, G["w_h"], G["b_h"], G["w1"],
-              G["b1"], G["w2"], G["b2"], G["emb"] if with_emb else None, n)
-    torch.testing.assert_close(G["w1"].cpu(), 2 * r_g["w1"], rtol=1e-3,
-                               atol=4e-4 * float(r_g["w1"].abs().max()))
+    # three routes to the same gradients: the matrix-core kernel (default where it has a tiling:
+    # C in 16/32/64), the vector kernel recomputing the forward, and the vector kernel fed with the
+    # forward's saved pre-activations
+    def run_bwd(G, d_enc, pre):
+        capi.call("shade_bwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
+                  Pd["w2"], Pd["b2"], emb, dv(d_logit), dv(d_rgb), d_enc, G["w_h"], G["b_h"], G["w1"],
+                  G["b1"], G["w2"], G["b2"], G["emb"] if with_emb else None, pre, n)
+
+    for route in ("default", "valu", "valu_saved_pre"):
+        monkeypatch.setenv("F2N_SHADE_BWD", "valu" if route != "default" else "auto")
+        d_enc = torch.full((C, n), 7.0, device=dev)      # must be overwritten
+        G = {k: torch.zeros_like(v) for k, v in Pd.items()}
+        run_bwd(G, d_enc, pre_cm if route == "valu_saved_pre" else None)
+        tag = lambda m, k: "%s [%s]: %s" % (k, route, m)
+        torch.testing.assert_close(d_enc.t().cpu(), r_denc, rtol=1e-3,
+                                   atol=1e-4 * float(r_denc.abs().max()),
+                                   msg=lambda m: tag(m, "d_enc"))
+        for k in ("w_h", "b_h", "w1", "b1", "w2", "b2") + (("emb",) if with_emb else ()):
+            ref = r_g[k]
+            torch.testing.assert_close(G[k].cpu(), ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max()),
+                                       msg=lambda m, k=k: tag(m, k))
+        # accumulate semantics of the parameter gradients
+        run_bwd(G, d_enc, pre_cm if route == "valu_saved_pre" else None)
+        torch.testing.assert_close(G["w1"].cpu(), 2 * r_g["w1"], rtol=1e-3,
+                                   atol=4e-4 * float(r_g["w1"].abs().max()),
+                                   msg=lambda m: tag(m, "w1 accumulate"))
