@@ -262,20 +262,17 @@ public:
         w2.size(0) == 3 && w2.size(1) == 64,
       "shade: layer shapes must be 16xC, 64x32, 3x64");
     Tensor logit = torch::empty({n}, enc.options()), rgb = torch::empty({n, 3}, enc.options());
-    // hidden pre-activations are kept for the backward (what autograd saves for a ReLU) when a
-    // backward will follow; 256 B per sample, written and read coalesced
-    const bool keep_pre = torch::GradMode::is_enabled() &&
-                          (enc.requires_grad() || w1.requires_grad() || w_h.requires_grad());
-    Tensor pre_cm = keep_pre ? torch::empty({64, n}, enc.options()) : Tensor();
     f2n::check(
       f2n_shade_fwd(
         enc_cm.data_ptr<float>(), C, dirs.data_ptr<float>(), use_emb ? f2n::iptr(sample_img) : nullptr,
         f2n::fptr(w_h), f2n::fptr(b_h), f2n::fptr(w1), f2n::fptr(b1), f2n::fptr(w2), f2n::fptr(b2),
         f2n::fptr(emb), logit.data_ptr<float>(), rgb.data_ptr<float>(),
-        keep_pre ? pre_cm.data_ptr<float>() : nullptr, n, f2n::current_stream(enc_cm)),
+        /*pre_cm=*/nullptr,  // the matrix-core backward recomputes the hidden layer (cheaper than
+                             // 256 B per sample through HBM twice)
+        n, f2n::current_stream(enc_cm)),
       "f2n_shade_fwd");
     ctx->save_for_backward(
-      {enc_cm, dirs, use_emb ? sample_img : Tensor(), w_h, b_h, w1, b1, w2, b2, emb, pre_cm});
+      {enc_cm, dirs, use_emb ? sample_img : Tensor(), w_h, b_h, w1, b1, w2, b2, emb});
     return {logit, rgb};
   }
 
@@ -283,7 +280,7 @@ public:
   {
     auto sv = ctx->get_saved_variables();
     Tensor &enc_cm = sv[0], &dirs = sv[1], &sample_img = sv[2], &w_h = sv[3], &b_h = sv[4],
-           &w1 = sv[5], &b1 = sv[6], &w2 = sv[7], &b2 = sv[8], &emb = sv[9], &pre_cm = sv[10];
+           &w1 = sv[5], &b1 = sv[6], &w2 = sv[7], &b2 = sv[8], &emb = sv[9];
     const int C = (int)enc_cm.size(0);
     const int64_t n = enc_cm.size(1);
     auto opt = enc_cm.options();
@@ -304,7 +301,7 @@ public:
         f2n::fptr(emb), f2n::fptr(d_logit), f2n::fptr(d_rgb), d_enc_cm.data_ptr<float>(),
         g_w_h.data_ptr<float>(), g_b_h.data_ptr<float>(), g_w1.data_ptr<float>(),
         g_b1.data_ptr<float>(), g_w2.data_ptr<float>(), g_b2.data_ptr<float>(),
-        use_emb ? g_emb.data_ptr<float>() : nullptr, f2n::fptr(pre_cm), n,
+        use_emb ? g_emb.data_ptr<float>() : nullptr, /*pre_cm=*/nullptr, n,
         f2n::current_stream(enc_cm)),
       "f2n_shade_bwd");
     // d_enc goes back as an [n, C] view of channel-major storage: f2n_hash_bwd reads it in place

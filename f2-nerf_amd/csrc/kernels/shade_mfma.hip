@@ -82,8 +82,8 @@ struct MShape
   static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
 };
 
-// keeps the instruction scheduler from interleaving two phases (it otherwise hoists the next phase's
-// loads over a whole GEMM and spills the accumulators)
+// No instruction crosses a phase boundary: 5 % faster than letting the scheduler mix phases
+// (F2N_SHADE_VARIANT=1 lifts the fences, for measurements)
 template <int V>
 __device__ __forceinline__ void phase_fence_v()
 {
@@ -110,11 +110,18 @@ __device__ __forceinline__ void st_row(float * row, uint32_t byte_off, float v)
   *reinterpret_cast<float *>(reinterpret_cast<char *>(row) + byte_off) = v;
 }
 
-// max(x, 0) in one instruction: fmaxf adds a canonicalising v_max x, x in front.  (Not inline asm:
-// the hazard recogniser does not see an asm's read of a register an MFMA is still writing.)
+// Pins global loads where they are written: without it the scheduler sinks them to their first use,
+// ~200 MFMAs later, and the wave then waits a full memory latency there.
+__device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// max(x, 0) in one instruction: as integers, positive floats order like floats and every negative
+// float (and -0) is a negative integer.  fmaxf / v_med3 put a canonicalising v_max x, x in front.
+// (Not inline asm: the hazard recogniser does not see an asm's read of a register an MFMA is
+// still writing.)
 __device__ __forceinline__ float relu(float x)
 {
-  return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff());
+  const int b = __float_as_int(x);
+  return __int_as_float(b > 0 ? b : 0);
 }
 
 // sum over the 16 lanes of a quarter (a DPP row), result in every lane of the quarter
@@ -186,6 +193,15 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
   __syncthreads();
 
   const float * wop = lds_w + lane;  // slot s of this lane: wop[s * 64]
+  // With 512 registers the weight operands stay in registers for the whole kernel (C <= 32: 84 of
+  // them); read just in time from LDS they cost a full LDS latency every eight products.
+  constexpr bool kWReg = C <= 32;
+  float wreg[kWReg ? S::kSlots : 1];
+  if constexpr (kWReg) {
+#pragma unroll
+    for (int i = 0; i < S::kSlots; i++) wreg[i] = wop[i * 64];
+  }
+  auto W = [&](int slot) { return kWReg ? wreg[kWReg ? slot : 0] : wop[slot * 64]; };
   // byte offsets of this quarter's first enc / d_enc row (quarter q owns channels q*kS1.., rows 4q..)
   const uint32_t cE = (uint32_t)((int64_t)(q * kS1) * n * 4), cD = (uint32_t)((int64_t)(4 * q) * n * 4);
   const bool has_emb = (p_emb != nullptr) && (sample_img != nullptr);
@@ -198,6 +214,18 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
   float acc_b1[4];      // d b1[16M+m], partial over this quarter's k-steps (S-layout reads)
   f32x4 acc_bh = zero4; // d b_h[4q+r]
   float acc_b2 = 0.f;   // d b2[q]
+  f32x4 acc_emb = zero4;  // d emb[emb_img][4q+r], partial over this lane's samples
+  int emb_img = -1;
+  auto flush_emb = [&]() {
+    if (emb_img >= 0) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float t = quarter_sum(acc_emb[r]);
+        if (m == 0) atomicAdd(g_emb + (int64_t)emb_img * kOut1 + 4 * q + r, t);
+      }
+    }
+    acc_emb = zero4;
+  };
 #pragma unroll
   for (int M = 0; M < 4; M++) {
     acc_w1[M][0] = acc_w1[M][1] = zero4;
@@ -233,6 +261,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
     for (int k = 0; k < 3; k++) dir_[k] = ld_row(dirs + k, offL);
   };
   load_inputs(wave_global, eB, img, dir);
+  issue_fence();
 
   for (int64_t st = wave_global; st < n_strides; st += wave_count) {
     const int64_t s0 = st * 64;
@@ -254,7 +283,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
     for (int T = 0; T < 4; T++) h[T] = *reinterpret_cast<const f32x4 *>(lds_w + S::oBh + 4 * q);
 #pragma unroll
     for (int t = 0; t < kS1; t++) {
-      const float a = wop[(S::oWA1 + t) * 64];
+      const float a = W(S::oWA1 + t);
 #pragma unroll
       for (int T = 0; T < 4; T++) h[T] = mfma16(a, eB[t][T], h[T]);
     }
@@ -309,7 +338,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
           pre[M][T] = *reinterpret_cast<const f32x4 *>(lds_w + S::oB1 + 16 * M + 4 * q);
 #pragma unroll
         for (int t = 0; t < 8; t++) {
-          const float a = wop[(S::oWA2 + M * 8 + t) * 64];
+          const float a = W(S::oWA2 + M * 8 + t);
 #pragma unroll
           for (int T = 0; T < 4; T++)
             pre[M][T] = mfma16(a, (t < 4) ? Xh[T][t] : Xs[t - 4][T], pre[M][T]);
@@ -319,6 +348,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
 
     // ---- the next stride's inputs (their registers are free since the head layer / the SH block)
     load_inputs(st + wave_count, eB, img, dir);
+    issue_fence();
 
     phase_fence_v<V>();
     // ---- output layer on rows 0, 4, 8: o[c = q][s] in register 0, then d_o
@@ -327,6 +357,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
       float g_rgb[4];  // d_rgb[s][c = q]: in flight during the 64 products below
 #pragma unroll
       for (int T = 0; T < 4; T++) g_rgb[T] = ld_row(d_rgb, 3 * offS[T] + ((q < 3) ? 4 * q : 8));
+      issue_fence();
       f32x4 o[4];
 #pragma unroll
       for (int T = 0; T < 4; T++) {
@@ -337,7 +368,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
       for (int M = 0; M < 4; M++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const float a = wop[(S::oWA3 + M * 4 + r) * 64];
+          const float a = W(S::oWA3 + M * 4 + r);
 #pragma unroll
           for (int T = 0; T < 4; T++) o[T] = mfma16(a, relu(pre[M][T][r]), o[T]);
         }
@@ -389,7 +420,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
     // ---- back through the output layer and the ReLU: d_hid replaces pre
 #pragma unroll
     for (int M = 0; M < 4; M++) {
-      const float a = wop[(S::oWA4 + M) * 64];
+      const float a = W(S::oWA4 + M);
 #pragma unroll
       for (int T = 0; T < 4; T++) {
         const f32x4 dh = mfma16(a, d_o[T], zero4);
@@ -441,6 +472,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
     float g_logit[4];  // in flight during the products below
 #pragma unroll
     for (int T = 0; T < 4; T++) g_logit[T] = ld_row(d_logit, offS[T]);
+    issue_fence();
     f32x4 dX[4];
 #pragma unroll
     for (int T = 0; T < 4; T++) dX[T] = zero4;
@@ -448,21 +480,24 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
     for (int M = 0; M < 4; M++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const float a = wop[(S::oWA5 + M * 4 + r) * 64];
+        const float a = W(S::oWA5 + M * 4 + r);
 #pragma unroll
         for (int T = 0; T < 4; T++) dX[T] = mfma16(a, pre[M][T][r], dX[T]);
       }
 
     phase_fence_v<V>();
-    // ---- appearance embedding: d emb[img][i] += d_X[i]  (row 0 included: X[0] = 1 + emb[0])
+    // ---- appearance embedding: d emb[img][i] += d_X[i]  (row 0 included: X[0] = 1 + emb[0]).
+    // A chunk of rays usually comes from ONE image: its row's gradient is accumulated in registers
+    // and flushed when the image changes / at the end.  (One atomic per stride on the same 64 bytes,
+    // from every wave of the chip, serialises in L2: 6.9 ms instead of 1.7 ms per launch.)
     if (has_emb) {
       const int img0 = __builtin_amdgcn_readfirstlane(img_cur[0]);
       if (__all(img_cur[0] == img0 && img_cur[1] == img0 && img_cur[2] == img0 && img_cur[3] == img0)) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float t = quarter_sum(dX[0][r] + dX[1][r] + dX[2][r] + dX[3][r]);
-          if (m == 0) atomicAdd(g_emb + (int64_t)img0 * kOut1 + 4 * q + r, t);
+        if (img0 != emb_img) {
+          flush_emb();
+          emb_img = img0;
         }
+        acc_emb += (dX[0] + dX[1]) + (dX[2] + dX[3]);  // clamped samples carry zeros
       } else {
 #pragma unroll
         for (int T = 0; T < 4; T++)
@@ -492,7 +527,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
       for (int T = 0; T < 4; T++) de[T] = zero4;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const float a = wop[(S::oWA6 + M * 4 + r) * 64];
+        const float a = W(S::oWA6 + M * 4 + r);
 #pragma unroll
         for (int T = 0; T < 4; T++) de[T] = mfma16(a, d_h[T][r], de[T]);
       }
@@ -521,6 +556,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
   }
 
   // ---- flush this wave's accumulators
+  if (has_emb) flush_emb();
 #pragma unroll
   for (int M = 0; M < 4; M++) {
 #pragma unroll

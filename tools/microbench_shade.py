@@ -11,7 +11,9 @@ n, C, E = 65536 * 128, 32, 50
 g = torch.Generator(device=dev).manual_seed(0)
 enc = torch.randn(C, n, device=dev, generator=g) * 0.1
 dirs = torch.randn(n, 3, device=dev, generator=g); dirs /= dirs.norm(dim=1, keepdim=True)
-img = (torch.arange(n, device=dev) // 128 % E).to(torch.int32)
+# one chunk of rays = one view: every sample carries the same image id (worst case for the
+# embedding-gradient atomics)
+img = torch.full((n,), 7, device=dev, dtype=torch.int32)
 P = [torch.randn(16, C, device=dev) * .3, torch.randn(16, device=dev) * .1, torch.randn(64, 32, device=dev) * .3,
      torch.randn(64, device=dev) * .1, torch.randn(3, 64, device=dev) * .3, torch.randn(3, device=dev) * .1]
 emb = torch.randn(E, 16, device=dev) * .1
