@@ -164,10 +164,11 @@ std::pair<Tensor, Tensor> Hash3DAnchored::density_head() const
           mlp_->bias.detach().slice(0, 0, 1).contiguous()};
 }
 
-Tensor Hash3DAnchored::encode(const Tensor & points)
+Tensor Hash3DAnchored::encode(const Tensor & points, int64_t samples_per_ray)
 {
   auto info = torch::make_intrusive<Hash3DAnchoredInfo>();
   info->hash3d_ = this;
+  info->samples_per_ray_ = samples_per_ray;
 
   // scene contraction (reference .cpp:79-82: eight ATen launches) as one kernel each way
   Tensor x = ContractFn::apply(points)[0];
@@ -230,13 +231,24 @@ variable_list Hash3DAnchoredFunction::forward(
   Tensor out_cm = torch::empty({(int64_t)L * F, n}, points.options());
   {
     f2n::ScopedKernelTimer timer("hash_fwd", f2n::current_stream(points), (double)n);
-    f2n::check(
-      f2n_hash_fwd(
-        points.data_ptr<float>(), reinterpret_cast<const uint16_t *>(table16.data_ptr()),
-        field->prim_pool_.data_ptr<int32_t>(), field->bias_pool_.data_ptr<float>(),
-        field->level_mul_.data_ptr<float>(), out_cm.data_ptr<float>(), 1, n, nullptr, n, L, F,
-        (uint32_t)field->local_size_, field->level_stride_, f2n::current_stream(points)),
-      "f2n_hash_fwd");
+    const int64_t spr = info->samples_per_ray_;
+    if (spr > 0 && spr % 16 == 0 && n % spr == 0 && n / spr <= INT32_MAX) {
+      f2n::check(
+        f2n_hash_fwd_raytile(
+          points.data_ptr<float>(), reinterpret_cast<const uint16_t *>(table16.data_ptr()),
+          field->prim_pool_.data_ptr<int32_t>(), field->bias_pool_.data_ptr<float>(),
+          field->level_mul_.data_ptr<float>(), out_cm.data_ptr<float>(), (int)(n / spr), (int)spr, L,
+          F, (uint32_t)field->local_size_, field->level_stride_, f2n::current_stream(points)),
+        "f2n_hash_fwd_raytile");
+    } else {
+      f2n::check(
+        f2n_hash_fwd(
+          points.data_ptr<float>(), reinterpret_cast<const uint16_t *>(table16.data_ptr()),
+          field->prim_pool_.data_ptr<int32_t>(), field->bias_pool_.data_ptr<float>(),
+          field->level_mul_.data_ptr<float>(), out_cm.data_ptr<float>(), 1, n, nullptr, n, L, F,
+          (uint32_t)field->local_size_, field->level_stride_, f2n::current_stream(points)),
+        "f2n_hash_fwd");
+    }
   }
   Tensor out = out_cm.t();
   return {out};

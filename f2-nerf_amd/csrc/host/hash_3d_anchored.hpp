@@ -40,7 +40,9 @@ public:
 
   // contraction + hash encode only (no Linear): [n, L*F], stored channel-major.  The Renderer's
   // fused path feeds this straight into the fused per-sample network kernel.
-  Tensor encode(const Tensor & points);
+  // samples_per_ray > 0 declares `points` a dense ray-major [n_rays, samples_per_ray] grid: the
+  // forward then walks neighbouring rays per wavefront (f2n_hash_fwd_raytile), same results.
+  Tensor encode(const Tensor & points, int64_t samples_per_ray = 0);
 
   // Same autograd node as encode(), but the forward result is supplied: `enc_cm` [L*F, n]
   // channel-major, the encoding of exactly these points computed earlier (the Renderer's first pass).
@@ -86,6 +88,7 @@ class Hash3DAnchoredInfo : public torch::CustomClassHolder
 public:
   Hash3DAnchored * hash3d_ = nullptr;
   torch::Tensor precomputed_cm_;  // optional [L*F, n] encoding to return instead of computing it
+  int64_t samples_per_ray_ = 0;   // > 0: points are a dense [n_rays, samples_per_ray] grid
 };
 
 namespace torch::autograd

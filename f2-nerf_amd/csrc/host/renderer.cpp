@@ -86,7 +86,8 @@ RenderResult Renderer::render_fused(
     Tensor enc_kept_cm;
     {
       torch::NoGradGuard no_grad;
-      Tensor enc_all_cm = field.encode(all.pts).t();  // [C, n_all] contiguous storage
+      // all.pts is the dense [n_rays, S] grid of the sampler: ray-tile mapping of the encode
+      Tensor enc_all_cm = field.encode(all.pts, S).t();  // [C, n_all] contiguous storage
       TORCH_CHECK(enc_all_cm.is_contiguous(), "encode() must return channel-major storage");
       auto head = field.density_head();
       Tensor counts = torch::empty({n_rays}, iopt);

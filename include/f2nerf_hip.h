@@ -56,6 +56,18 @@ int f2n_hash_fwd(
   const float * mul, float * out, int64_t out_ld_point, int64_t out_ld_chan, uint32_t * idx_out,
   int64_t n, int L, int F, uint32_t T, int64_t level_stride, void * stream);
 
+/* f2n_hash_fwd for a DENSE sample grid: pts [n_rays, S, 3] ray-major as f2n_sample_rays writes it
+ * (the input of the first field evaluation, src/renderer.cpp:61), out_cm channel-major
+ * [L*F, n_rays*S] (element (p, c) at out_cm[c*n + p], 16-byte aligned).  Same arithmetic, same
+ * results; the lanes of a wavefront walk neighbouring RAYS at one sample index instead of
+ * consecutive samples of one ray, so image-ordered ray batches (src/renderer.cpp render of a whole
+ * view, src/main_functions/train_manager.cpp:170-190) share gathered table lines.
+ * F2N_E_UNSUPPORTED unless S is a multiple of 16: call f2n_hash_fwd instead. */
+int f2n_hash_fwd_raytile(
+  const float * pts, const uint16_t * table_f16, const int32_t * primes, const float * bias,
+  const float * mul, float * out_cm, int n_rays, int S, int L, int F, uint32_t T,
+  int64_t level_stride, void * stream);
+
 /* Hash3DAnchoredBackwardKernel<__half> + the /grad_scale epilogue
  * -- src/hash_3d_anchored.cu:95-145,190-215.
  *   grad_out    element (p, c) at grad_out[p*g_ld_point + c*g_ld_chan], f32

@@ -55,6 +55,29 @@ def test_hash_fwd_parity(capi, dev, L, F, log2_T, stride_mode):
     assert torch.equal(out_t.t().contiguous().cpu(), got)
 
 
+@pytest.mark.parametrize("L,F,T,n_rays,S", [
+    (16, 2, 1 << 19, 333, 128),   # reference configuration, ragged last ray tile
+    (4, 8, 1 << 12, 64, 16),      # exactly one tile
+    (3, 1, 1000, 130, 48),        # T not a power of two
+    (2, 4, 1 << 10, 1, 32),       # a single ray
+])
+def test_hash_fwd_raytile_matches_oracle(capi, dev, L, F, T, n_rays, S):
+    """The ray-tile mapping (lanes = neighbouring rays at one depth) changes which thread computes a
+    sample, not what is computed: bit-exact against the oracle, like f2n_hash_fwd."""
+    import math
+    fld = util.make_field(L, F, max(1, math.ceil(math.log2(T))), T * F, seed=L + F)
+    n = n_rays * S
+    pts = util.ball_points(n, seed=11)
+    ref, _ = K.hash_fwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], L, F, T,
+                        fld["stride"], want_idx=True)
+    d = _to(dev, pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"])
+    out = torch.full((L * F, n), 7.0, device=dev)
+    capi.call("hash_fwd_raytile", *d, out, n_rays, S, L, F, T, fld["stride"])
+    _assert_hash_values(out.t().contiguous().cpu(), ref)
+    with pytest.raises(capi.F2NError):   # S must be a multiple of 16
+        capi.call("hash_fwd_raytile", *d, out, n_rays, S - 1, L, F, T, fld["stride"])
+
+
 def test_hash_fwd_non_pow2_T_and_empty(capi, dev):
     L, F, T = 4, 2, 1000
     fld = util.make_field(L, F, 10, T * F, seed=3)

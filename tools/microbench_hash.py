@@ -35,7 +35,11 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--points", default="rays", choices=["rays", "ball"])
+    ap.add_argument("--points", default="rays", choices=["rays", "ball", "view", "view_sm"],
+                    help="rays: random rays, samples of a ray consecutive; view: 65536 consecutive pixels of "
+                         "an 800-wide pinhole view (focal 1111, camera at distance 1), ray-major as the "
+                         "renderer emits them; view_sm: the same points sample-major (lane = adjacent pixel)")
+    ap.add_argument("--fwd-only", action="store_true")
     args = ap.parse_args()
     capi = importlib.import_module("f2-nerf_amd").capi
     dev = torch.device("cuda:0")
@@ -66,6 +70,22 @@ def main():
         nrm = p.norm(dim=1, keepdim=True)
         pts = torch.where(nrm <= 1, p, (2 - 1 / nrm) * p / nrm).contiguous()
         n = pts.shape[0]
+    elif args.points in ("view", "view_sm"):
+        S, R, W, f = 128, n // 128, 800, 1111.1
+        pix = torch.arange(R, device=dev)
+        i, j = (pix // W).float(), (pix % W).float()
+        # camera at (1, 0, 0) looking at the origin (-x), pixel (i, j) -> direction
+        d = torch.stack([-torch.ones_like(i), (j - 400) / f, -(i - 400) / f], 1)
+        d = d / d.norm(dim=1, keepdim=True)
+        o = torch.tensor([1.0, 0.0, 0.0], device=dev).expand(R, 3)
+        t = ((torch.arange(S, device=dev).float() + 0.5) * (4.0 / S)).reshape(1, S, 1)
+        p = (o[:, None] + d[:, None] * t)                      # [R, S, 3]
+        if args.points == "view_sm":
+            p = p.transpose(0, 1)                              # [S, R, 3]
+        p = p.reshape(-1, 3)
+        nrm = p.norm(dim=1, keepdim=True)
+        pts = torch.where(nrm <= 1, p, (2 - 1 / nrm) * p / nrm).contiguous()
+        n = pts.shape[0]
     else:
         dd = torch.randn(n, 3, device=dev, generator=g)
         pts = (dd / dd.norm(dim=1, keepdim=True) * torch.rand(n, 1, device=dev, generator=g) ** (1 / 3) * 2).contiguous()
@@ -79,6 +99,13 @@ def main():
         med, best = timeit(lambda: capi.call("hash_fwd", pts, table16, primes, bias, mul, out, ldp, ldc,
                                              None, n, L, F, T, stride), args.reps)
         print("  %-28s %8.3f ms (best %8.3f)  %7.1f GB/s algorithmic" % (name, med, best, n * bytes_fwd / med / 1e6))
+    if args.points in ("rays", "view") and n % 128 == 0:
+        med, best = timeit(lambda: capi.call("hash_fwd_raytile", pts, table16, primes, bias, mul, out_cm,
+                                             n // 128, 128, L, F, T, stride), args.reps)
+        print("  %-28s %8.3f ms (best %8.3f)  %7.1f GB/s algorithmic" %
+              ("fwd ray-tile [C,n]", med, best, n * bytes_fwd / med / 1e6))
+    if args.fwd_only:
+        return
     grad_rm = torch.randn(n, C, device=dev, generator=g) * 1e-3
     grad_cm = grad_rm.t().contiguous()
     tg = torch.zeros(numel, device=dev)
