@@ -29,6 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -98,9 +99,24 @@ def algorithmic_bytes(kernel, L, F, S):
     raise KeyError(kernel)
 
 
+def algorithmic_flops(kernel, L, F):
+    """f32 flops one sample needs in the per-sample network kernels (2 per multiply-add, no padding):
+    head C x 16, hidden 32 x 64, output 64 x 3; the backward recomputes the forward and adds the
+    data gradients (64 x 3, 64 x 16, 16 x C) and the weight gradients (3 x 64, 64 x 32, 16 x C)."""
+    C = L * F
+    fwd = 16 * C + 32 * 64 + 64 * 3
+    if kernel == "shade_fwd":
+        return 2 * fwd
+    if kernel == "shade_bwd":
+        return 2 * (fwd + (64 * 3 + 64 * 16 + 16 * C) + (3 * 64 + 64 * 32 + 16 * C))
+    raise KeyError(kernel)
+
+
 # kernels behind each hipEvent-timed operator, for the PMC traffic lookup
 OP_KERNELS = {
-    "hash_fwd": ["hash_fwd_kernel"],
+    "hash_fwd": ["hash_fwd_kernel", "hash_fwd_raytile_kernel"],
+    "shade_fwd": ["shade_fwd_kernel"],
+    "shade_bwd": ["shade_bwd_mfma_kernel", "shade_bwd_kernel"],
     "hash_bwd": ["hash_bwd_bin_kernel", "hash_bwd_reduce_kernel"],
     "density_march": ["density_march_kernel"],
     "density_scan": ["density_scan_kernel"],
@@ -300,15 +316,24 @@ def main():
         rays_total = n_rays_view * args.steps * world
         kernels = {}
         for name, (launches, total_ms, units) in timings.items():
-            b = algorithmic_bytes(name, L, F, S)
             kernels[name] = {
                 "launches": launches, "avg_ms": total_ms / max(launches, 1),
                 "units_per_launch": units / max(launches, 1),
-                "algorithmic_bytes_per_unit": b,
-                "achieved_GBs": (units * b) / (total_ms * 1e-3) / 1e9 if total_ms > 0 else None,
                 "share_of_step": total_ms * 1e-3 / (elapsed * 1.0),
             }
-        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if kernels else None
+            if name.startswith("shade"):   # matrix-core / vector f32 work: priced in flops
+                fl = algorithmic_flops(name, L, F)
+                tf = (units * fl) / (total_ms * 1e-3) / 1e12 if total_ms > 0 else None
+                kernels[name].update({"algorithmic_flops_per_unit": fl, "achieved_TFLOPs": tf,
+                                      "f32_peak_TFLOPs": F32_PEAK_TFLOPS,
+                                      "frac_of_f32_peak": tf / F32_PEAK_TFLOPS if tf else None})
+            else:
+                b = algorithmic_bytes(name, L, F, S)
+                kernels[name].update({
+                    "algorithmic_bytes_per_unit": b,
+                    "achieved_GBs": (units * b) / (total_ms * 1e-3) / 1e9 if total_ms > 0 else None})
+        hbm = [k for k in kernels if "achieved_GBs" in kernels[k]]
+        dom = max(hbm, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if hbm else None
         roofline = None
         if dom:
             a = kernels[dom]["achieved_GBs"]

@@ -3,6 +3,8 @@
 // host halves: FlexOps.cu:96-216, CustomOps.cu:69-118, Scatter.cu:43-132, CustomOps.cpp:10-20).
 #include "ragged_ops.hpp"
 
+#include "kernel_timer.hpp"
+
 using torch::Tensor;
 using torch::autograd::AutogradContext;
 using torch::autograd::variable_list;
@@ -262,6 +264,8 @@ public:
         w2.size(0) == 3 && w2.size(1) == 64,
       "shade: layer shapes must be 16xC, 64x32, 3x64");
     Tensor logit = torch::empty({n}, enc.options()), rgb = torch::empty({n, 3}, enc.options());
+    {
+    f2n::ScopedKernelTimer timer("shade_fwd", f2n::current_stream(enc_cm), (double)n);
     f2n::check(
       f2n_shade_fwd(
         enc_cm.data_ptr<float>(), C, dirs.data_ptr<float>(), use_emb ? f2n::iptr(sample_img) : nullptr,
@@ -271,6 +275,7 @@ public:
                              // 256 B per sample through HBM twice)
         n, f2n::current_stream(enc_cm)),
       "f2n_shade_fwd");
+    }
     ctx->save_for_backward(
       {enc_cm, dirs, use_emb ? sample_img : Tensor(), w_h, b_h, w1, b1, w2, b2, emb});
     return {logit, rgb};
@@ -294,6 +299,8 @@ public:
            g_w2 = torch::zeros_like(w2), g_b2 = torch::zeros_like(b2);
     const bool use_emb = emb.defined() && sample_img.defined();
     Tensor g_emb = use_emb ? torch::zeros_like(emb) : Tensor();  // undefined = no gradient
+    {
+    f2n::ScopedKernelTimer timer("shade_bwd", f2n::current_stream(enc_cm), (double)n);
     f2n::check(
       f2n_shade_bwd(
         enc_cm.data_ptr<float>(), C, dirs.data_ptr<float>(), use_emb ? f2n::iptr(sample_img) : nullptr,
@@ -304,6 +311,7 @@ public:
         use_emb ? g_emb.data_ptr<float>() : nullptr, /*pre_cm=*/nullptr, n,
         f2n::current_stream(enc_cm)),
       "f2n_shade_bwd");
+    }
     // d_enc goes back as an [n, C] view of channel-major storage: f2n_hash_bwd reads it in place
     return {d_enc_cm.t(), Tensor(), Tensor(), g_w_h, g_b_h, g_w1, g_b1, g_w2, g_b2, g_emb};
   }
