@@ -79,11 +79,9 @@ def fox_like_poses(n, seed=2022):
 
 
 def view_rays(H, pose, intr, h, w):
-    ii, jj = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=pose.device),
-                            torch.arange(w, dtype=torch.float32, device=pose.device), indexing="ij")
-    ij = torch.stack([ii.reshape(-1), jj.reshape(-1)], -1)
-    o, d = H.get_rays_from_pose(pose.unsqueeze(0), intr.unsqueeze(0), ij)
-    return o.contiguous(), d.contiguous()
+    """All pixels of one view, row-major: one f2n_gen_rays launch (no pixel-grid tensor)."""
+    o, d = H.get_view_rays(pose, intr, h, w)
+    return o, d
 
 
 def algorithmic_bytes(kernel, L, F, S):

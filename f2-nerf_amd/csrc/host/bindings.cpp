@@ -92,6 +92,18 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     Rays r = get_rays_from_pose(pose, intr, ij);
     return py::make_tuple(r.origins, r.dirs);
   });
+  m.def("get_view_rays", [](const Tensor & pose, const Tensor & intr, int h, int w) {
+    Rays r = get_view_rays(pose, intr, h, w);
+    return py::make_tuple(r.origins, r.dirs);
+  });
+  m.def(
+    "sample_random_rays",
+    [](const Tensor & poses, const Tensor & intr, int h, int w, int64_t n, const Tensor & images) {
+      auto [r, gt, cam] = sample_random_rays(poses, intr, h, w, n, images);
+      return py::make_tuple(r.origins, r.dirs, gt, cam);
+    },
+    py::arg("poses"), py::arg("intrinsics"), py::arg("h"), py::arg("w"), py::arg("batch_size"),
+    py::arg("images") = Tensor());
   m.def("manual_seed", [](uint64_t s) { torch::manual_seed(s); });
   m.def("kernel_timer_enable", &f2n::kernel_timer_enable);
   m.def("kernel_timer_collect", []() {

@@ -304,10 +304,7 @@ std::tuple<Tensor, Tensor> Renderer::render_all_rays(
 std::tuple<Tensor, Tensor> Renderer::render_image(
   const Tensor & pose, const Tensor & intrinsic, const int h, const int w, const int batch_size)
 {
-  const auto fopt = f2n::float_on(pose.device());
-  auto grid = torch::meshgrid({torch::arange(h, fopt), torch::arange(w, fopt)}, "ij");
-  Tensor ij = torch::stack({grid[0].reshape({-1}), grid[1].reshape({-1})}, -1);
-  Rays rays = get_rays_from_pose(pose.unsqueeze(0), intrinsic.unsqueeze(0), ij);
+  Rays rays = get_view_rays(pose, intrinsic, h, w);  // pixel grid generated in the kernel
   auto [colors, depths] = render_all_rays(rays.origins, rays.dirs, batch_size);
   colors = colors.reshape({h, w, 3}).clip(0.f, 1.f);
   depths = depths.reshape({h, w, 1}).repeat({1, 1, 3});

@@ -149,6 +149,19 @@ int f2n_scatter_add_bwd(
 
 /* ------------------------------------------------------------------ sampler (rows A4, A5) ----- */
 
+/* get_rays_from_pose -- src/rays.cpp:7-28, for both callers: a view's pixel grid
+ * (src/renderer.cpp:153-172, src/dataset.cpp:128-146) and the random training batch with one camera
+ * per ray (src/dataset.cpp:150-171, without its index_select of poses and intrinsics).
+ *   poses      [n_cams] blocks of pose_ld floats: a row-major [3,4] (pose_ld = 12) or [4,4] (16)
+ *   intrinsics [n_cams, 3, 3]
+ *   cam_idx    [n] i32 camera of each ray; NULL: camera 0 when n_cams == 1, camera r when n_cams == n
+ *   ij         [n, 2] i32 (row, col); NULL: ray r is pixel first_pixel + r of a `width`-wide image
+ *   rays_o, rays_d [n, 3]: origin = t, dir = R . ((col+.5-cx)/fx, -(row+.5-cy)/fy, -1), not normalised */
+int f2n_gen_rays(
+  const float * poses, int pose_ld, const float * intrinsics, int64_t n_cams,
+  const int32_t * cam_idx, const int32_t * ij, int64_t first_pixel, int width, float * rays_o,
+  float * rays_d, int64_t n, void * stream);
+
 /* PtsSampler::get_samples (about 20 ATen launches) -- src/points_sampler.cpp:20-64.
  *   noise   [n_rays, S] f32 step multipliers (TRAIN: U[0.5,1.5)), or NULL for all-ones (VALIDATE)
  *   outputs pts [n_rays*S, 3], dirs [n_rays*S, 3], dt [n_rays*S], t [n_rays*S], bounds [n_rays,2]

@@ -348,3 +348,52 @@ def test_sample_rays(capi, dev, S, step, train):
     # dt is a difference of nearby points (quirk Q7): absolute error ~ ulp(|p|), relative to dt ~1e-4
     torch.testing.assert_close(o_dt.cpu(), dt, rtol=1e-3, atol=2e-6)
     assert (o_dt.cpu().reshape(n, S)[:, 0] == 0).all()
+
+
+# --------------------------------------------------------------------------- ray generation ----
+
+
+def test_gen_rays_against_oracle(capi, dev):
+    """f2n_gen_rays in its three addressing modes against the oracle's restatement of
+    get_rays_from_pose (reference src/rays.cpp:7-28).  Origins are copies (exact); directions are a
+    3-term dot product whose order the reference's matmul does not fix: 1e-6."""
+    from oracle import ref_render as R
+    g = torch.Generator().manual_seed(4)
+    E, h, w = 5, 37, 53
+    poses = torch.randn(E, 3, 4, generator=g)
+    K = torch.tensor([[1111.1, 0, w / 2], [0, 1100.0, h / 2], [0, 0, 1.0]]).repeat(E, 1, 1)
+    K[:, 0, 0] += torch.arange(E) * 3.0
+    d_poses, d_K = poses.to(dev), K.to(dev)
+
+    # (1) a view's pixel grid, no ij tensor, starting in the middle of the image
+    first, n = 100, h * w - 100
+    o = torch.empty(n, 3, device=dev)
+    d = torch.empty(n, 3, device=dev)
+    capi.call("gen_rays", d_poses[2:3].contiguous(), 12, d_K[2:3].contiguous(), 1, None, None, first, w, o, d, n)
+    px = torch.arange(first, first + n)
+    ij = torch.stack([px // w, px % w], 1).float()
+    ro, rd = R.get_rays_from_pose(poses[2:3], K[2:3], ij)
+    assert torch.equal(o.cpu(), ro)
+    torch.testing.assert_close(d.cpu(), rd, rtol=1e-6, atol=1e-6)
+
+    # (2) random batch: one camera per ray through cam_idx (src/dataset.cpp:150-171)
+    n = 1000
+    cam = torch.randint(0, E, (n,), generator=g).to(torch.int32)
+    ij = torch.stack([torch.randint(0, h, (n,), generator=g), torch.randint(0, w, (n,), generator=g)], 1)
+    o = torch.empty(n, 3, device=dev)
+    d = torch.empty(n, 3, device=dev)
+    capi.call("gen_rays", d_poses, 12, d_K, E, cam.to(dev), ij.to(torch.int32).to(dev).contiguous(), 0, 1, o, d, n)
+    ro, rd = R.get_rays_from_pose(poses[cam.long()], K[cam.long()], ij.float())
+    assert torch.equal(o.cpu(), ro)
+    torch.testing.assert_close(d.cpu(), rd, rtol=1e-6, atol=1e-6)
+
+    # (3) one [4,4] pose per ray, no cam_idx
+    p44 = torch.cat([poses[cam.long()], torch.tensor([0., 0, 0, 1]).expand(n, 1, 4)], 1).contiguous()
+    o2 = torch.empty(n, 3, device=dev)
+    d2 = torch.empty(n, 3, device=dev)
+    capi.call("gen_rays", p44.to(dev), 16, d_K[cam.long().to(dev)].contiguous(), n, None,
+              ij.to(torch.int32).to(dev).contiguous(), 0, 1, o2, d2, n)
+    assert torch.equal(o2, o) and torch.equal(d2, d)
+
+    with pytest.raises(capi.F2NError):   # 7 cameras for 1000 rays and no cam_idx
+        capi.call("gen_rays", d_poses, 12, d_K, 7, None, None, 0, w, o, d, n)

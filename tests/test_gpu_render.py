@@ -190,3 +190,34 @@ def test_shadow_table_tracks_optimizer(host, dev):
         assert torch.equal(f.table_f16(), f.feat_pool.detach().to(torch.float16))
     assert not torch.equal(f.table_f16(), t0)
     assert all(math.isfinite(x) for x in losses)
+
+
+def test_view_rays_and_random_batches(host, dev):
+    """get_view_rays == get_rays_from_pose on the explicit pixel grid; sample_random_rays returns
+    rays, colours and camera ids that belong together (reference src/dataset.cpp:150-171)."""
+    g = torch.Generator().manual_seed(8)
+    E, h, w = 4, 24, 40
+    poses = torch.randn(E, 3, 4, generator=g).to(dev)
+    K = torch.tensor([[300.0, 0, w / 2], [0, 310.0, h / 2], [0, 0, 1.0]]).repeat(E, 1, 1).to(dev)
+    ii, jj = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32),
+                            indexing="ij")
+    ij = torch.stack([ii.reshape(-1), jj.reshape(-1)], -1).to(dev)
+    o1, d1 = host.get_rays_from_pose(poses[1:2], K[1:2], ij)
+    o2, d2 = host.get_view_rays(poses[1], K[1], h, w)
+    assert torch.equal(o1, o2) and torch.equal(d1, d2)
+
+    images = torch.rand(E, h, w, 3, generator=g).to(dev)
+    n = 512
+    o, d, gt, cam = host.sample_random_rays(poses, K, h, w, n, images)
+    assert o.shape == (n, 3) and d.shape == (n, 3) and gt.shape == (n, 3) and cam.dtype == torch.int32
+    assert int(cam.min()) >= 0 and int(cam.max()) < E
+    # recover each ray's pixel from its direction, then check origin, colour and camera agree
+    R = poses[cam.long(), :, :3].cpu().double()      # random matrices, not rotations: solve R dc = d
+    dc = torch.linalg.solve(R, d.cpu().double().unsqueeze(-1)).squeeze(-1).float().to(dev)
+    col = dc[:, 0] / -dc[:, 2] * K[cam.long(), 0, 0] + K[cam.long(), 0, 2] - 0.5
+    row = -dc[:, 1] / -dc[:, 2] * K[cam.long(), 1, 1] + K[cam.long(), 1, 2] - 0.5
+    ri, ci = row.round().long(), col.round().long()
+    assert float((row - ri).abs().max()) < 1e-2 and float((col - ci).abs().max()) < 1e-2
+    assert int(ri.min()) >= 0 and int(ri.max()) < h and int(ci.min()) >= 0 and int(ci.max()) < w
+    assert torch.equal(o, poses[cam.long(), :, 3])
+    assert torch.equal(gt, images[cam.long(), ri, ci])
