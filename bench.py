@@ -56,6 +56,11 @@ def parse_args():
     ap.add_argument("--rays", type=int, default=0,
                     help="rays per step per GPU instead of a full view (e.g. 512 = BASELINE config C4 "
                          "with --samples 1024); pixels drawn at random like dataset.cpp:153-155")
+    ap.add_argument("--train-iters", type=int, default=0,
+                    help="after the headline measurement, time K complete data-parallel TRAINING "
+                         "iterations of the reference's own shape (512 random rays per GPU drawn on the "
+                         "device, 1024 samples, fwd + bwd + gradient all-reduce + fused Adam; SURVEY 8f "
+                         "ranks 1, 2, 4) and report them as \"train_iteration\" -- not part of value")
     return ap.parse_args()
 
 
@@ -204,6 +209,47 @@ def cpu_baseline(args, n_rays):
                          max(1, len(times) - 1))}
 
 
+def time_train_iterations(args, pkg, H, dev, dist, world, poses, intr):
+    """K complete training iterations of the reference's batch (train_manager.cpp:66-107 minus
+    logging): 512 rays per rank drawn on the device, S = 1024 / step 1/256, TRAIN render + loss +
+    backward, gradient average over the ranks (two collectives), fused Adam with the f16 shadow."""
+    ren = H.Renderer(args.n_images, n_levels=args.levels, n_channels=args.channels,
+                     log2_table=args.log2_table, max_samples=1024, step=1.0 / 256)
+    with torch.no_grad():
+        ren.named_parameters()["scene_field.feat_pool"].normal_(0.0, 0.1)
+    opt = ren.make_fused_adam(1e-2)
+    images = torch.rand(args.n_images, 64, 64, 3, device=dev)   # stand-in ground truth, 64x64 per image
+    intr_small = intr.clone()
+    intr_small[:2] *= 64.0 / args.width
+    intr_all = intr_small[None].expand(args.n_images, 3, 3).contiguous()
+    n_coll = 0
+
+    def iteration():
+        nonlocal n_coll
+        o, d, gt, cam = H.sample_random_rays(poses, intr_all, 64, 64, 512, images)
+        ren.zero_grad()
+        ren.train_step(o, d, cam, gt, 0.0)
+        n_coll = pkg.sharding.allreduce_gradients(list(ren.grads().values()), dist)
+        opt.step()
+
+    for _ in range(3):
+        iteration()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_iters):
+        iteration()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.train_iters * 1e3
+    return {"ms": ms, "rays_per_iteration": 512 * world, "iterations": args.train_iters,
+            "collectives_per_iteration": n_coll,
+            "note": "reference batch shape (confs/train_config.yaml:4, points_sampler.hpp:15,39): "
+                    "fwd + bwd + gradient all-reduce + fused Adam; not part of value"}
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -304,6 +350,10 @@ def main():
         opt_ms[name] = (time.perf_counter() - t1) / 5 * 1e3
         del opt
 
+    train_iter = None
+    if args.train_iters > 0:
+        train_iter = time_train_iterations(args, pkg, H, dev, dist, world, poses, intr)
+
     t_max = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
@@ -361,6 +411,8 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
         }
+        if train_iter is not None:
+            out["train_iteration"] = train_iter
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.cpu_rays)

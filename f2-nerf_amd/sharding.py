@@ -5,6 +5,9 @@ with replicated parameters and no data-path collective.  The only exchange is on
 per step of {sum of squared colour error, number of values}, from which every rank derives the
 global MSE / PSNR (PSNR as in the reference: 20*log10(1/sqrt(mse)), train_manager.cpp:96).
 With the "nccl" backend this is RCCL over xGMI: a 16-byte payload, latency-bound.
+
+Data-parallel TRAINING (beyond the north star's render metric) additionally
+averages the parameter gradients: `allreduce_gradients`.
 """
 import math
 
@@ -38,3 +41,42 @@ def reduce_error_stats(sq_err_sum, n_values, dist=None, group=None):
 def psnr_from_stats(stat):
     mse = float(stat[0] / stat[1])
     return 20.0 * math.log10(1.0 / math.sqrt(mse)), mse
+
+
+def allreduce_gradients(grads, dist=None, group=None, small_bucket_bytes=1 << 20):
+    """Average the parameter gradients over the ranks, in place (data-parallel training: every rank
+    rendered its own rays with the same parameters; the loss is a mean over rays, so the global
+    gradient is the mean of the local ones when the ranks hold equally many rays).
+
+    grads: iterable of tensors (undefined / None entries are skipped).  Sized for xGMI rings, which are
+    per-link bound: the hash table's gradient (64 MiB at the reference size) is reduced IN PLACE as
+    one collective -- no flatten copy of the one tensor that matters -- and everything below
+    `small_bucket_bytes` (the MLPs, the embedding: ~20 KiB) rides in ONE flattened bucket, so a step
+    costs two collectives instead of one per parameter.  Returns the number of collectives issued."""
+    grads = [g for g in grads if g is not None and torch.is_tensor(g)]
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1 or not grads:
+        return 0
+    world = dist.get_world_size(group)
+    big = [g for g in grads if g.numel() * g.element_size() >= small_bucket_bytes]
+    small = [g for g in grads if g.numel() * g.element_size() < small_bucket_bytes]
+    n_coll = 0
+    for g in big:
+        t = g if g.is_contiguous() else g.contiguous()
+        dist.all_reduce(t, group=group)
+        t.div_(world)
+        if t is not g:
+            g.copy_(t)
+        n_coll += 1
+    by_type = {}
+    for g in small:
+        by_type.setdefault((g.dtype, g.device), []).append(g)
+    for gs in by_type.values():
+        flat = torch.cat([g.reshape(-1) for g in gs])
+        dist.all_reduce(flat, group=group)
+        flat.div_(world)
+        off = 0
+        for g in gs:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        n_coll += 1
+    return n_coll
