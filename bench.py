@@ -56,6 +56,11 @@ def parse_args():
     ap.add_argument("--rays", type=int, default=0,
                     help="rays per step per GPU instead of a full view (e.g. 512 = BASELINE config C4 "
                          "with --samples 1024); pixels drawn at random like dataset.cpp:153-155")
+    ap.add_argument("--render-images", type=int, default=0,
+                    help="after the headline measurement, time K inference renders of a full view "
+                         "(Renderer::render_image, VALIDATE mode, forward only; the reference's own "
+                         "self-reported figure is seconds per rendered image, src/main_functions/"
+                         "test.cpp:35-57) and report them as \"render_image\" -- not part of value")
     ap.add_argument("--train-iters", type=int, default=0,
                     help="after the headline measurement, time K complete data-parallel TRAINING "
                          "iterations of the reference's own shape (512 random rays per GPU drawn on the "
@@ -350,6 +355,20 @@ def main():
         opt_ms[name] = (time.perf_counter() - t1) / 5 * 1e3
         del opt
 
+    render_img = None
+    if args.render_images > 0:
+        with torch.no_grad():
+            ren.render_image(poses[0], intr, args.height, args.width, args.chunk)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(args.render_images):
+                ren.render_image(poses[(k + 1) % args.n_images], intr, args.height, args.width, args.chunk)
+            torch.cuda.synchronize()
+        ms_img = (time.perf_counter() - t1) / args.render_images * 1e3
+        render_img = {"ms_per_image": ms_img, "rays_per_s": args.height * args.width / ms_img * 1e3,
+                      "images": args.render_images,
+                      "note": "%dx%d, %d samples/ray, VALIDATE (no jitter), forward only, one GPU; "
+                              "not part of value" % (args.height, args.width, S)}
     train_iter = None
     if args.train_iters > 0:
         train_iter = time_train_iterations(args, pkg, H, dev, dist, world, poses, intr)
@@ -413,6 +432,8 @@ def main():
         }
         if train_iter is not None:
             out["train_iteration"] = train_iter
+        if render_img is not None:
+            out["render_image"] = render_img
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, args.cpu_rays)
