@@ -48,9 +48,9 @@ constexpr float kEps = 1e-3f;
 template <int C>
 struct MShape
 {
-  static_assert(C % 16 == 0 && C <= 64, "MFMA path: C must be 16, 32 or 64");
+  static_assert(C % 8 == 0 && C <= 64, "MFMA path: C must be 8, 16, 32 or 64");
   static constexpr int kS1 = C / 4;    // k-steps of the head layer (quarter q owns channels q*kS1 ..)
-  static constexpr int kM6 = C / 16;   // 16-channel tiles of enc
+  static constexpr int kM6 = (C + 15) / 16;  // 16-channel tiles of enc (C = 8: half a tile, zero padded)
   // weight operand slots (64 floats each, one per lane)
   static constexpr int oWA1 = 0;               // [t]        w_h[m][q*kS1 + t]
   static constexpr int oWA2 = oWA1 + kS1;      // [M*8 + t]  w1[16M+m][kappa2(t, q)]
@@ -69,7 +69,7 @@ struct MShape
                                                // ds_read_b128's four 16-lane groups (68 is 2-way)
   static constexpr int oXS = 0;                // [32][kP]  X
   static constexpr int oES = oXS + 32 * kP;    // [C][kP]   enc
-  static constexpr int oPS = oES + C * kP;     // [16][kP]  one M-tile of relu(pre) / d_hid, then d_h
+  static constexpr int oPS = oES + kM6 * 16 * kP;  // [16][kP]  one M-tile of relu(pre) / d_hid, then d_h
   static constexpr int oDS = oPS + 16 * kP;    // [4][kP]   d_o rows 0..2, row 3 = 0
   static constexpr int kWaveFloats = oDS + 4 * kP;
   // One wave per SIMD.  The live state of a stride (64 pre-activations, 65 accumulators, operands in
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
       v = p_w1[(16 * M + 4 * q + r) * kIn2 + m];
     } else {
       const int M = (slot - S::oWA6) >> 2, r = (slot - S::oWA6) & 3;
-      v = p_w_h[(4 * q + r) * C + 16 * M + m];
+      v = (16 * M + m < C) ? p_w_h[(4 * q + r) * C + 16 * M + m] : 0.f;
     }
     lds_w[i] = v;
   }
@@ -190,6 +190,9 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
   float * PS = tile + S::oPS;
   float * DS = tile + S::oDS;
   DS[3 * kP + lane] = 0.f;  // the zero row read by lanes m >= 3 in the d w2 product
+  if constexpr (C % 16 != 0) {  // enc rows beyond C (read as zeros by the d w_h product)
+    for (int r = C; r < kM6 * 16; r++) ES[r * kP + lane] = 0.f;
+  }
   __syncthreads();
 
   const float * wop = lds_w + lane;  // slot s of this lane: wop[s * 64]
@@ -535,7 +538,9 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
       for (int T = 0; T < 4; T++)
         if (vT[T]) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) st_row(d_enc + (int64_t)(16 * M + r) * n, offS[T] + cD, de[T][r]);
+          for (int r = 0; r < 4; r++)
+            if (C % 16 == 0 || 16 * M + 4 * q + r < C)
+              st_row(d_enc + (int64_t)(16 * M + r) * n, offS[T] + cD, de[T][r]);
         }
     }
 
@@ -578,7 +583,8 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
 #pragma unroll
   for (int N = 0; N < kM6; N++)
 #pragma unroll
-    for (int r = 0; r < 4; r++) atomicAdd(g_w_h + (4 * q + r) * C + 16 * N + m, acc_wh[N][r]);
+    for (int r = 0; r < 4; r++)
+      if (C % 16 == 0 || 16 * N + m < C) atomicAdd(g_w_h + (4 * q + r) * C + 16 * N + m, acc_wh[N][r]);
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const float t = quarter_sum(acc_bh[r]);
@@ -597,7 +603,7 @@ namespace f2n_detail
 
 bool shade_bwd_mfma_supports(int C, int64_t n)
 {
-  return (C == 16 || C == 32 || C == 64) && (int64_t)C * n < ((int64_t)1 << 30);
+  return (C == 8 || C == 16 || C == 32 || C == 64) && (int64_t)C * n < ((int64_t)1 << 30);
 }
 
 int launch_shade_bwd_mfma(
@@ -628,6 +634,7 @@ int launch_shade_bwd_mfma(
     default: F2N_LAUNCH_MFMA_V(CC, 0) break; \
   }
   switch (C) {
+    case 8: F2N_LAUNCH_MFMA(8) break;
     case 16: F2N_LAUNCH_MFMA(16) break;
     case 32: F2N_LAUNCH_MFMA(32) break;
     case 64: F2N_LAUNCH_MFMA(64) break;

@@ -59,7 +59,7 @@ def test_shade_fwd_bwd(capi, dev, monkeypatch, C, n, with_emb):
     torch.testing.assert_close(rgb.cpu(), r_rgb, rtol=1e-4, atol=1e-5)
 
     # three routes to the same gradients: the matrix-core kernel (default where it has a tiling:
-    # C in 16/32/64), the vector kernel recomputing the forward, and the vector kernel fed with the
+    # C in 8/16/32/64), the vector kernel recomputing the forward, and the vector kernel fed with the
     # forward's saved pre-activations
     def run_bwd(G, d_enc, pre):
         capi.call("shade_bwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
