@@ -498,6 +498,13 @@ extern "C" int f2n_shade_fwd(
   if (n == 0) return F2N_OK;
   if (!enc_cm || !dirs || !w_h || !b_h || !w1 || !b1 || !w2 || !b2 || !logit || !rgb)
     return F2N_E_INVALID_ARG;
+  // matrix-core forward (shade_mfma.hip) unless F2N_SHADE_FWD=vector asks for the one-sample-per-lane
+  // kernel below (A/B measurements) or n is beyond its 32-bit offsets
+  const char * froute = std::getenv("F2N_SHADE_FWD");
+  if (!(froute && std::strcmp(froute, "vector") == 0) && f2n_detail::shade_bwd_mfma_supports(64, n))
+    return f2n_detail::launch_shade_fwd_mfma(
+      enc_cm, C, dirs, sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, logit, rgb, pre_cm, n,
+      (hipStream_t)stream);
   const dim3 grid(f2n_div_up(n, F2N_BLOCK)), block(F2N_BLOCK);
   F2N_DISPATCH_C(C, hipLaunchKernelGGL(
                       (shade_fwd_kernel<CC>), grid, block, 0, (hipStream_t)stream, enc_cm, dirs,

@@ -596,6 +596,186 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
   }
 }
 
+
+// ---- forward on the matrix cores ------------------------------------------------------------------
+// The forward third of the kernel above (head, hidden and output layer in the Q-layout, no lane
+// movement), two waves per SIMD: no accumulators live across strides, so 256 registers suffice and
+// the second wave hides the first one's loads.  LDS: the three forward weight operands (56 slots at
+// C = 32) + a 16-row tile per wave that moves SH16(dir) from lane = sample into the Q-layout.
+template <int C>
+struct FShape
+{
+  static_assert(C % 8 == 0 && C <= 64, "MFMA path: C must be 8, 16, 32 or 64");
+  static constexpr int kS1 = C / 4;
+  static constexpr int oWA1 = 0, oWA2 = oWA1 + kS1, oWA3 = oWA2 + 32, kSlots = oWA3 + 16;
+  static constexpr int oBh = kSlots * 64, oB1 = oBh + 16, oB2 = oB1 + 64, kWFloats = oB2 + 4;
+  static constexpr int kP = 68;             // [16][kP] SH tile per wave (b32 accesses only)
+  static constexpr int kWaveFloats = 16 * kP;
+  static constexpr int kWaves = 12;  // three per SIMD: the kernel needs 136 registers
+  static constexpr int kLdsFloats = kWFloats + kWaves * kWaveFloats;
+};
+
+template <int C>
+__global__ __launch_bounds__(FShape<C>::kWaves * 64) void shade_fwd_mfma_kernel(
+  const float * __restrict__ enc, const float * __restrict__ dirs,
+  const int32_t * __restrict__ sample_img, const float * __restrict__ p_w_h,
+  const float * __restrict__ p_b_h, const float * __restrict__ p_w1,
+  const float * __restrict__ p_b1, const float * __restrict__ p_w2,
+  const float * __restrict__ p_b2, const float * __restrict__ p_emb, float * __restrict__ logit,
+  float * __restrict__ rgb, float * __restrict__ pre_out, int64_t n)
+{
+  using S = FShape<C>;
+  constexpr int kS1 = S::kS1, kP = S::kP;
+  __shared__ __attribute__((aligned(16))) float lds_all[S::kLdsFloats];
+  float * lds_w = lds_all;
+  for (int i = threadIdx.x; i < S::kSlots * 64; i += S::kWaves * 64) {
+    const int slot = i >> 6, l = i & 63, q = l >> 4, m = l & 15;
+    float v;
+    if (slot < S::oWA2) {
+      v = p_w_h[m * C + q * kS1 + (slot - S::oWA1)];
+    } else if (slot < S::oWA3) {
+      const int M = (slot - S::oWA2) >> 3, t = (slot - S::oWA2) & 7;
+      v = p_w1[(16 * M + m) * kIn2 + ((t < 4) ? 4 * q + t : 16 + 4 * q + (t - 4))];
+    } else {
+      const int M = (slot - S::oWA3) >> 2, r = (slot - S::oWA3) & 3;
+      v = ((m & 3) == 0 && m < 12) ? p_w2[(m >> 2) * kHid + 16 * M + 4 * q + r] : 0.f;
+    }
+    lds_w[i] = v;
+  }
+  if (threadIdx.x < 16) lds_w[S::oBh + threadIdx.x] = p_b_h[threadIdx.x];
+  if (threadIdx.x < 64) lds_w[S::oB1 + threadIdx.x] = p_b1[threadIdx.x];
+  if (threadIdx.x < 4) lds_w[S::oB2 + threadIdx.x] = (threadIdx.x < 3) ? p_b2[threadIdx.x] : 0.f;
+  __syncthreads();
+
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int q = lane >> 4, m = lane & 15;
+  float * XS = lds_all + S::kWFloats + wave * S::kWaveFloats;  // SH rows 0..15 of this wave
+  const float * wop = lds_w + lane;
+  const uint32_t cE = (uint32_t)((int64_t)(q * kS1) * n * 4);
+  const bool has_emb = (p_emb != nullptr) && (sample_img != nullptr);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  const int64_t n_strides = (n + 63) / 64;
+  const int64_t wave_count = (int64_t)gridDim.x * S::kWaves;
+  for (int64_t st = (int64_t)blockIdx.x * S::kWaves + wave; st < n_strides; st += wave_count) {
+    const int64_t s0 = st * 64;
+    bool vT[4];
+    uint32_t offS[4];
+#pragma unroll
+    for (int T = 0; T < 4; T++) {
+      const int64_t s = s0 + 16 * T + m;
+      vT[T] = s < n;
+      offS[T] = (uint32_t)((vT[T] ? s : n - 1) * 4);
+    }
+    float eB[kS1][4];
+#pragma unroll
+    for (int t = 0; t < kS1; t++)
+#pragma unroll
+      for (int T = 0; T < 4; T++) eB[t][T] = ld_row(enc + (int64_t)t * n, offS[T] + cE);
+    int img[4] = {0, 0, 0, 0};
+    if (has_emb) {
+#pragma unroll
+      for (int T = 0; T < 4; T++) img[T] = ld_row(sample_img, offS[T]);
+    }
+    float dir[3];
+    {
+      const uint32_t offL = (uint32_t)(((s0 + lane < n) ? s0 + lane : n - 1) * 12);
+#pragma unroll
+      for (int k = 0; k < 3; k++) dir[k] = ld_row(dirs + k, offL);
+    }
+    issue_fence();
+
+    // ---- head layer
+    f32x4 h[4];
+#pragma unroll
+    for (int T = 0; T < 4; T++) h[T] = *reinterpret_cast<const f32x4 *>(lds_w + S::oBh + 4 * q);
+#pragma unroll
+    for (int t = 0; t < kS1; t++) {
+      const float a = wop[(S::oWA1 + t) * 64];
+#pragma unroll
+      for (int T = 0; T < 4; T++) h[T] = mfma16(a, eB[t][T], h[T]);
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int T = 0; T < 4; T++)
+        if (vT[T]) st_row(logit, offS[T], h[T][0]);
+    }
+
+    // ---- shader input
+    f32x4 Xh[4];
+    {
+      f32x4 e4[4];
+      if (has_emb) {
+#pragma unroll
+        for (int T = 0; T < 4; T++)
+          e4[T] = *reinterpret_cast<const f32x4 *>(p_emb + (int64_t)img[T] * kOut1 + 4 * q);
+      }
+      float sh[16];
+      sh_basis<4>(dir[0], dir[1], dir[2], sh);
+#pragma unroll
+      for (int k = 0; k < 16; k++) XS[k * kP + lane] = sh[k];
+#pragma unroll
+      for (int T = 0; T < 4; T++) {
+        Xh[T] = h[T];
+        if (q == 0) Xh[T][0] = 1.f;
+        if (has_emb) Xh[T] += e4[T];
+      }
+    }
+    wave_lds_sync();
+    float Xs[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int T = 0; T < 4; T++) Xs[t][T] = XS[(4 * q + t) * kP + 16 * T + m];
+    wave_lds_sync();
+
+    // ---- hidden layer, then the output layer on rows 0, 4, 8
+    f32x4 o[4];
+#pragma unroll
+    for (int T = 0; T < 4; T++) {
+      o[T] = zero4;
+      o[T][0] = lds_w[S::oB2 + q];
+    }
+#pragma unroll
+    for (int M = 0; M < 4; M++) {
+      f32x4 pre[4];
+#pragma unroll
+      for (int T = 0; T < 4; T++)
+        pre[T] = *reinterpret_cast<const f32x4 *>(lds_w + S::oB1 + 16 * M + 4 * q);
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const float a = wop[(S::oWA2 + M * 8 + t) * 64];
+#pragma unroll
+        for (int T = 0; T < 4; T++)
+          pre[T] = mfma16(a, (t < 4) ? Xh[T][t] : Xs[t - 4][T], pre[T]);
+      }
+      if (pre_out) {
+#pragma unroll
+        for (int T = 0; T < 4; T++)
+          if (vT[T]) {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              st_row(pre_out + (int64_t)(16 * M + r) * n, offS[T] + (uint32_t)((int64_t)(4 * q) * n * 4),
+                     pre[T][r]);
+          }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float a = wop[(S::oWA3 + M * 4 + r) * 64];
+#pragma unroll
+        for (int T = 0; T < 4; T++) o[T] = mfma16(a, relu(pre[T][r]), o[T]);
+      }
+    }
+    if (q < 3) {
+#pragma unroll
+      for (int T = 0; T < 4; T++)
+        if (vT[T])
+          st_row(rgb + q, 3 * offS[T], (1.f + 2.f * kEps) / (1.f + expf(-o[T][0])) - kEps);
+    }
+  }
+}
+
 }  // namespace
 
 namespace f2n_detail
@@ -642,6 +822,34 @@ int launch_shade_bwd_mfma(
   }
 #undef F2N_LAUNCH_MFMA
 #undef F2N_LAUNCH_MFMA_V
+  return f2n_launch_status();
+}
+
+
+int launch_shade_fwd_mfma(
+  const float * enc_cm, int C, const float * dirs, const int32_t * sample_img, const float * w_h,
+  const float * b_h, const float * w1, const float * b1, const float * w2, const float * b2,
+  const float * app_emb, float * logit, float * rgb, float * pre_cm, int64_t n, hipStream_t stream)
+{
+  const int64_t n_strides = (n + 63) / 64;
+  if (app_emb && (reinterpret_cast<uintptr_t>(app_emb) & 15u)) return F2N_E_INVALID_ARG;
+  if ((int64_t)64 * n >= ((int64_t)1 << 30)) return F2N_E_UNSUPPORTED;  // 32-bit byte offsets (pre_cm)
+#define F2N_LAUNCH_FWD(CC)                                                                         \
+  {                                                                                                \
+    constexpr int kW = FShape<CC>::kWaves;                                                         \
+    const unsigned grid = (unsigned)std::min<int64_t>(256, (n_strides + kW - 1) / kW);             \
+    hipLaunchKernelGGL(                                                                            \
+      (shade_fwd_mfma_kernel<CC>), dim3(grid), dim3(kW * 64), 0, stream, enc_cm, dirs, sample_img, \
+      w_h, b_h, w1, b1, w2, b2, app_emb, logit, rgb, pre_cm, n);                                   \
+  }
+  switch (C) {
+    case 8: F2N_LAUNCH_FWD(8) break;
+    case 16: F2N_LAUNCH_FWD(16) break;
+    case 32: F2N_LAUNCH_FWD(32) break;
+    case 64: F2N_LAUNCH_FWD(64) break;
+    default: return F2N_E_UNSUPPORTED;
+  }
+#undef F2N_LAUNCH_FWD
   return f2n_launch_status();
 }
 

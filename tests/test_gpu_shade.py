@@ -53,10 +53,22 @@ def test_shade_fwd_bwd(capi, dev, monkeypatch, C, n, with_emb):
     logit = torch.empty(n, device=dev)
     rgb = torch.empty(n, 3, device=dev)
     pre_cm = torch.empty(64, n, device=dev)
-    capi.call("shade_fwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
-              Pd["w2"], Pd["b2"], emb, logit, rgb, pre_cm, n)
-    torch.testing.assert_close(logit.cpu(), r_logit, rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(rgb.cpu(), r_rgb, rtol=1e-4, atol=1e-5)
+    # forward: the vector kernel (default) and the matrix-core kernel (F2N_SHADE_FWD=mfma)
+    pre_first = None
+    for froute in ("mfma", "vector"):
+        monkeypatch.setenv("F2N_SHADE_FWD", froute)
+        logit.fill_(7.0)
+        rgb.fill_(7.0)
+        pre_cm.fill_(7.0)
+        capi.call("shade_fwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
+                  Pd["w2"], Pd["b2"], emb, logit, rgb, pre_cm, n)
+        torch.testing.assert_close(logit.cpu(), r_logit, rtol=1e-4, atol=1e-5, msg=lambda m: froute + " logit: " + m)
+        torch.testing.assert_close(rgb.cpu(), r_rgb, rtol=1e-4, atol=1e-5, msg=lambda m: froute + " rgb: " + m)
+        if pre_first is None:
+            pre_first = pre_cm.clone()
+        else:   # the hidden pre-activations the two kernels hand to a backward agree
+            torch.testing.assert_close(pre_cm, pre_first, rtol=1e-4, atol=1e-5)
+    monkeypatch.delenv("F2N_SHADE_FWD")
 
     # three routes to the same gradients: the matrix-core kernel (default where it has a tiling:
     # C in 8/16/32/64), the vector kernel recomputing the forward, and the vector kernel fed with the

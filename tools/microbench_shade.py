@@ -29,7 +29,10 @@ def t(fn, reps=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 pre = torch.empty(64, n, device=dev)
-print("fwd %.3f ms" % t(lambda: capi.call("shade_fwd", enc, C, dirs, img, *P, emb, logit, rgb, None, n)))
+print("fwd matrix-core (default) %.3f ms" % t(lambda: capi.call("shade_fwd", enc, C, dirs, img, *P, emb, logit, rgb, None, n)))
+os.environ["F2N_SHADE_FWD"] = "vector"
+print("fwd vector                %.3f ms" % t(lambda: capi.call("shade_fwd", enc, C, dirs, img, *P, emb, logit, rgb, None, n)))
+os.environ.pop("F2N_SHADE_FWD")
 print("fwd + save pre %.3f ms" % t(lambda: capi.call("shade_fwd", enc, C, dirs, img, *P, emb, logit, rgb, pre, n)))
 bwd = lambda pre_: capi.call("shade_bwd", enc, C, dirs, img, *P, emb, dl, dr, denc, *G, pre_, n)
 os.environ["F2N_SHADE_BWD"] = "auto"
