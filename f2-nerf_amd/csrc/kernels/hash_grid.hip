@@ -477,6 +477,8 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
   }
 }
 
+constexpr int kRegionsInFlight = 8;  // regions a wave loads before it accumulates them
+
 template <int F>
 __global__ __launch_bounds__(kSliceBlock) void hash_bwd_reduce_kernel(
   const uint32_t * __restrict__ ws_records, const uint32_t * __restrict__ ws_counts,
@@ -502,19 +504,19 @@ __global__ __launch_bounds__(kSliceBlock) void hash_bwd_reduce_kernel(
   for (int64_t t0 = (int64_t)wave * 64; t0 < n_tiles; t0 += (int64_t)kWaves * 64) {
     const uint32_t my_cnt = (t0 + lane < n_tiles) ? counts[t0 + lane] : 0u;
     const int n_here = (int)min((int64_t)64, n_tiles - t0);
-    for (int j0 = 0; j0 < n_here; j0 += 4) {
-      uint32_t cnt[4];
+    for (int j0 = 0; j0 < n_here; j0 += kRegionsInFlight) {
+      uint32_t cnt[kRegionsInFlight];
       uint32_t cnt_max = 0u;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < kRegionsInFlight; u++) {
         cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (j0 + u) & 63);
         if ((j0 + u) >= n_here) cnt[u] = 0u;
         cnt_max = max(cnt_max, cnt[u]);
       }
       for (int h = 0; h < n_half && (uint32_t)(64 * h) < cnt_max; h++) {  // wave-uniform bound
-        uint32_t rec[4][RW];
+        uint32_t rec[kRegionsInFlight][RW];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kRegionsInFlight; u++) {
           const bool live = (j0 + u) < n_here;
           const uint32_t * region = base + (size_t)(t0 + (live ? j0 + u : 0)) * tile_stride;
           // branch-free load so the four loads are in flight together: lanes past the region's
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(kSliceBlock) void hash_bwd_reduce_kernel(
           }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < kRegionsInFlight; u++) {
           if ((uint32_t)(lane + 64 * h) < cnt[u]) {
 #pragma unroll
             for (int k = 0; k < F; k++) {
