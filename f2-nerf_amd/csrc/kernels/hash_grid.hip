@@ -455,16 +455,39 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       }
     }
     __syncthreads();
-    // flush: wave w copies the queues of slices w, w+16, ... to their workspace regions
+    // flush: wave w copies the queues of slices w, w+16, ... to their workspace regions; the LDS
+    // reads of up to four slices are issued before the first store so their latencies overlap
     uint32_t * region0 = ws_records + ((size_t)l * n_tiles + tile) * n_slices * (size_t)qcap * RW;
-    for (int sidx = wave; sidx < n_slices; sidx += kBinBlock / 64) {
-      const uint32_t cnt = min(qcount[sidx], (uint32_t)qcap);
-      const uint32_t * q = queue + (size_t)sidx * qcap * RW;
-      uint32_t * dst = region0 + (size_t)sidx * qcap * RW;
-      if constexpr (RW == 2) {
-        for (uint32_t i = lane; i < cnt; i += 64)
-          reinterpret_cast<uint2 *>(dst)[i] = reinterpret_cast<const uint2 *>(q)[i];
-      } else {
+    if constexpr (RW == 2) {
+      constexpr int kWavesPerBlock = kBinBlock / 64;
+      for (int s0 = wave; s0 < n_slices; s0 += 4 * kWavesPerBlock) {
+        uint2 v[4][4];
+        uint32_t cnt[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          const int sidx = s0 + a * kWavesPerBlock;
+          cnt[a] = sidx < n_slices ? min(qcount[sidx], (uint32_t)qcap) : 0u;
+          const uint2 * q = reinterpret_cast<const uint2 *>(queue + (size_t)sidx * qcap * RW);
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if ((uint32_t)(lane + 64 * k) < cnt[a]) v[a][k] = q[lane + 64 * k];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+          const int sidx = s0 + a * kWavesPerBlock;
+          uint2 * dst = reinterpret_cast<uint2 *>(region0 + (size_t)sidx * qcap * RW);
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if ((uint32_t)(lane + 64 * k) < cnt[a]) dst[lane + 64 * k] = v[a][k];
+          for (uint32_t i = lane + 256; i < cnt[a]; i += 64)  // qcap > 256 (small slice counts)
+            dst[i] = reinterpret_cast<const uint2 *>(queue + (size_t)sidx * qcap * RW)[i];
+        }
+      }
+    } else {
+      for (int sidx = wave; sidx < n_slices; sidx += kBinBlock / 64) {
+        const uint32_t cnt = min(qcount[sidx], (uint32_t)qcap);
+        const uint32_t * q = queue + (size_t)sidx * qcap * RW;
+        uint32_t * dst = region0 + (size_t)sidx * qcap * RW;
         for (uint32_t i = lane; i < cnt * RW; i += 64) dst[i] = q[i];
       }
     }
