@@ -89,8 +89,52 @@ def case_render_small():
     return _np(out)
 
 
+def case_rays():
+    """get_rays_from_pose (reference src/rays.cpp:7-28): five cameras, one camera per ray."""
+    g = torch.Generator().manual_seed(21)
+    E, h, w, n = 5, 37, 53, 200
+    poses = torch.randn(E, 3, 4, generator=g)
+    K3 = torch.tensor([[1111.1, 0, w / 2], [0, 1100.0, h / 2], [0, 0, 1.0]]).repeat(E, 1, 1)
+    K3[:, 0, 0] += torch.arange(E) * 3.0
+    cam = torch.randint(0, E, (n,), generator=g).to(torch.int32)
+    ij = torch.stack([torch.randint(0, h, (n,), generator=g), torch.randint(0, w, (n,), generator=g)],
+                     1).to(torch.int32)
+    o, d = R.get_rays_from_pose(poses[cam.long()], K3[cam.long()], ij.float())
+    return _np(dict(poses=poses, intrinsics=K3, cam_idx=cam, ij=ij, rays_o=o, rays_d=d))
+
+
+def case_shade_network():
+    """The per-sample network between encode and compositing (reference
+    src/hash_3d_anchored.cpp:86, src/renderer.cpp:93-104, src/sh_shader.cpp:22-29) with torch
+    autograd for every gradient: 333 samples, C = 32, embedding ids that change inside a stride."""
+    g = torch.Generator().manual_seed(31)
+    n, C, E, eps = 333, 32, 5, 1e-3
+    enc = (torch.randn(n, C, generator=g) * 0.1).to(torch.float16).float().requires_grad_(True)
+    dirs = torch.randn(n, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    img = (torch.arange(n) // 37 % E).to(torch.int32)
+    P = {"w_h": torch.randn(16, C, generator=g) * 0.3, "b_h": torch.randn(16, generator=g) * 0.1,
+         "w1": torch.randn(64, 32, generator=g) * 0.3, "b1": torch.randn(64, generator=g) * 0.1,
+         "w2": torch.randn(3, 64, generator=g) * 0.3, "b2": torch.randn(3, generator=g) * 0.1,
+         "emb": torch.randn(E, 16, generator=g) * 0.1}
+    P = {k: v.requires_grad_(True) for k, v in P.items()}
+    d_logit, d_rgb = torch.randn(n, generator=g), torch.randn(n, 3, generator=g)
+    h = enc @ P["w_h"].t() + P["b_h"]
+    X = torch.cat([torch.ones_like(h[:, :1]), h[:, 1:]], 1) + P["emb"][img.long()]
+    X = torch.cat([X, K.sh_encode(dirs, 4)], 1)
+    o = torch.relu(X @ P["w1"].t() + P["b1"]) @ P["w2"].t() + P["b2"]
+    rgb = (1 + 2 * eps) / (1 + torch.exp(-o)) - eps
+    ((h[:, 0] * d_logit).sum() + (rgb * d_rgb).sum()).backward()
+    out = dict(enc=enc, dirs=dirs, img=img, d_logit=d_logit, d_rgb=d_rgb, logit=h[:, 0], rgb=rgb,
+               d_enc=enc.grad)
+    for k, v in P.items():
+        out["param." + k] = v
+        out["grad." + k] = v.grad
+    return _np(out)
+
+
 CASES = {"hash_ref_config": case_hash_ref_config, "segments": case_segments, "sh": case_sh,
-         "render_small": case_render_small}
+         "render_small": case_render_small, "rays": case_rays, "shade_network": case_shade_network}
 
 
 if __name__ == "__main__":

@@ -95,3 +95,51 @@ def test_render_against_golden(dev):
         assert ((g["scene_field.feat_pool"].cpu() - ref).norm() / ref.norm()) < 2e-4
         torch.testing.assert_close(g["app_emb"].cpu(), z["app_emb_grad"], rtol=1e-3,
                                    atol=1e-4 * float(z["app_emb_grad"].abs().max()))
+
+
+def test_raytile_and_rays_against_golden(capi, dev):
+    """f2n_hash_fwd_raytile on the golden points read as a 16 x 16 sample grid; f2n_gen_rays on the
+    stored cameras and pixels."""
+    z = _load("hash_ref_config")
+    fld = util.make_field(16, 2, 19, None, seed=2022)
+    d = [t.to(dev) for t in (z["pts"], fld["table16"], z["primes"], z["bias"], z["mul"])]
+    out = torch.empty(32, 256, device=dev)
+    capi.call("hash_fwd_raytile", *d, out, 16, 16, 16, 2, fld["T"], fld["stride"])
+    assert torch.equal(out.t().contiguous().cpu(), z["out"])
+    r = _load("rays")
+    n = r["ij"].shape[0]
+    o = torch.empty(n, 3, device=dev)
+    dd = torch.empty(n, 3, device=dev)
+    capi.call("gen_rays", r["poses"].to(dev), 12, r["intrinsics"].to(dev), r["poses"].shape[0],
+              r["cam_idx"].to(dev), r["ij"].to(dev).contiguous(), 0, 1, o, dd, n)
+    assert torch.equal(o.cpu(), r["rays_o"])
+    torch.testing.assert_close(dd.cpu(), r["rays_d"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("fwd_route,bwd_route", [("mfma", "auto"), ("vector", "valu")])
+def test_shade_network_against_golden(capi, dev, monkeypatch, fwd_route, bwd_route):
+    """f2n_shade_fwd / f2n_shade_bwd (matrix-core and vector kernels) against the stored outputs and
+    gradients of the op-by-op network."""
+    z = _load("shade_network")
+    monkeypatch.setenv("F2N_SHADE_FWD", fwd_route)
+    monkeypatch.setenv("F2N_SHADE_BWD", bwd_route)
+    n, C = z["enc"].shape
+    dv = lambda t: t.to(dev).contiguous()
+    enc_cm = dv(z["enc"].t())
+    P = {k: dv(z["param." + k]) for k in ("w_h", "b_h", "w1", "b1", "w2", "b2", "emb")}
+    logit, rgb = torch.empty(n, device=dev), torch.empty(n, 3, device=dev)
+    args = (enc_cm, C, dv(z["dirs"]), dv(z["img"]), P["w_h"], P["b_h"], P["w1"], P["b1"], P["w2"], P["b2"],
+            P["emb"])
+    capi.call("shade_fwd", *args, logit, rgb, None, n)
+    torch.testing.assert_close(logit.cpu(), z["logit"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rgb.cpu(), z["rgb"], rtol=1e-4, atol=1e-5)
+    G = {k: torch.zeros_like(v) for k, v in P.items()}
+    d_enc = torch.empty(C, n, device=dev)
+    capi.call("shade_bwd", *args, dv(z["d_logit"]), dv(z["d_rgb"]), d_enc, G["w_h"], G["b_h"], G["w1"],
+              G["b1"], G["w2"], G["b2"], G["emb"], None, n)
+    torch.testing.assert_close(d_enc.t().cpu(), z["d_enc"], rtol=1e-3,
+                               atol=1e-4 * float(z["d_enc"].abs().max()))
+    for k in G:
+        ref = z["grad." + k]
+        torch.testing.assert_close(G[k].cpu(), ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max()),
+                                   msg=lambda m, k=k: k + ": " + m)
