@@ -104,6 +104,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     },
     py::arg("poses"), py::arg("intrinsics"), py::arg("h"), py::arg("w"), py::arg("batch_size"),
     py::arg("images") = Tensor());
+  m.def("train_loss", &f2n::train_loss, py::arg("colors"), py::arg("gt_colors"), py::arg("var"),
+        py::arg("var_loss_weight"));
   m.def("manual_seed", [](uint64_t s) { torch::manual_seed(s); });
   m.def("kernel_timer_enable", &f2n::kernel_timer_enable);
   m.def("kernel_timer_collect", []() {

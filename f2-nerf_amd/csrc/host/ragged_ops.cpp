@@ -294,11 +294,24 @@ public:
     Tensor d_rgb = grad_output[1].defined() ? f2n::dev_f32(grad_output[1], "d_rgb")
                                             : torch::zeros({n, 3}, opt);
     Tensor d_enc_cm = torch::empty({(int64_t)C, n}, opt);
-    Tensor g_w_h = torch::zeros_like(w_h), g_b_h = torch::zeros_like(b_h),
-           g_w1 = torch::zeros_like(w1), g_b1 = torch::zeros_like(b1),
-           g_w2 = torch::zeros_like(w2), g_b2 = torch::zeros_like(b2);
+    // the seven small parameter gradients are views of ONE zero-filled buffer (one fill launch
+    // instead of seven; each view starts 16-byte aligned)
     const bool use_emb = emb.defined() && sample_img.defined();
-    Tensor g_emb = use_emb ? torch::zeros_like(emb) : Tensor();  // undefined = no gradient
+    auto pad4 = [](int64_t v) { return (v + 3) / 4 * 4; };
+    const int64_t sizes[7] = {w_h.numel(), b_h.numel(), w1.numel(), b1.numel(),
+                              w2.numel(), b2.numel(), use_emb ? emb.numel() : 0};
+    int64_t total = 0;
+    for (int64_t v : sizes) total += pad4(v);
+    Tensor gbuf = torch::zeros({total}, opt);
+    int64_t off = 0;
+    auto take = [&](const Tensor & like, int64_t numel) {
+      Tensor v = gbuf.narrow(0, off, numel).view(like.sizes());
+      off += pad4(numel);
+      return v;
+    };
+    Tensor g_w_h = take(w_h, sizes[0]), g_b_h = take(b_h, sizes[1]), g_w1 = take(w1, sizes[2]),
+           g_b1 = take(b1, sizes[3]), g_w2 = take(w2, sizes[4]), g_b2 = take(b2, sizes[5]);
+    Tensor g_emb = use_emb ? take(emb, sizes[6]) : Tensor();  // undefined = no gradient
     {
     f2n::ScopedKernelTimer timer("shade_bwd", f2n::current_stream(enc_cm), (double)n);
     f2n::check(
@@ -314,6 +327,44 @@ public:
     }
     // d_enc goes back as an [n, C] view of channel-major storage: f2n_hash_bwd reads it in place
     return {d_enc_cm.t(), Tensor(), Tensor(), g_w_h, g_b_h, g_w1, g_b1, g_w2, g_b2, g_emb};
+  }
+};
+
+
+class TrainLossFn : public torch::autograd::Function<TrainLossFn>
+{
+public:
+  static variable_list forward(
+    AutogradContext * ctx, Tensor colors, Tensor gt, Tensor var, double var_weight)
+  {
+    colors = f2n::dev_f32(colors, "train_loss colors");
+    gt = f2n::dev_f32(gt, "train_loss gt_colors");
+    var = f2n::dev_f32(var, "train_loss var");
+    const int64_t n_rays = colors.size(0);
+    TORCH_CHECK(
+      colors.dim() == 2 && colors.size(1) == 3 && gt.sizes() == colors.sizes() &&
+        var.numel() == n_rays && n_rays > 0 && n_rays <= INT32_MAX,
+      "train_loss: colors/gt [n_rays,3], var [n_rays]");
+    Tensor d_colors = torch::empty_like(colors), d_var = torch::empty({n_rays}, colors.options());
+    Tensor partial = torch::empty({f2n_loss_workspace_floats((int)n_rays)}, colors.options());
+    Tensor out = torch::empty({4}, colors.options());
+    f2n::check(
+      f2n_loss_fwd(
+        colors.data_ptr<float>(), gt.data_ptr<float>(), var.data_ptr<float>(), (int)n_rays,
+        (float)var_weight, d_colors.data_ptr<float>(), d_var.data_ptr<float>(),
+        partial.data_ptr<float>(), out.data_ptr<float>(), f2n::current_stream(colors)),
+      "f2n_loss_fwd");
+    ctx->save_for_backward({d_colors, d_var});
+    ctx->saved_data["var_shape"] = var.sizes().vec();
+    return {out};
+  }
+
+  static variable_list backward(AutogradContext * ctx, variable_list grad_output)
+  {
+    auto sv = ctx->get_saved_variables();
+    Tensor g = grad_output[0].select(0, 0);  // only the loss element carries gradient
+    Tensor d_var = (sv[1] * g).view(ctx->saved_data["var_shape"].toIntVector());
+    return {sv[0] * g, Tensor(), d_var, Tensor()};
   }
 };
 
@@ -389,4 +440,10 @@ f2n::CompositeOut f2n::composite(
 {
   auto out = CompositeFn::apply(field_out, rgb, dt, t, idx_start_end, bg_color);
   return {out[0], out[1], out[2]};
+}
+
+Tensor f2n::train_loss(
+  const Tensor & colors, const Tensor & gt_colors, const Tensor & var, float var_loss_weight)
+{
+  return TrainLossFn::apply(colors, gt_colors, var, (double)var_loss_weight)[0];
 }

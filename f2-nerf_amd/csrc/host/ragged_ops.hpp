@@ -69,6 +69,13 @@ ShadeOut shade(
   const Tensor & b_h, const Tensor & w1, const Tensor & b1, const Tensor & w2, const Tensor & b2,
   const Tensor & app_emb);
 
+// The loss of the training iteration (reference src/main_functions/train_manager.cpp:78-96) as one
+// autograd node over f2n_loss_fwd: returns [4] = {loss, color_loss, var_loss, sum of squared colour
+// error}; differentiable in colors [n_rays, 3] and var [n_rays] through element 0 (the others carry no
+// gradient).  loss = mean sqrt((colors-gt)^2 + 1e-4) + var_loss_weight * mean sqrt(var + 1e-2).
+Tensor train_loss(
+  const Tensor & colors, const Tensor & gt_colors, const Tensor & var, float var_loss_weight);
+
 // C = L*F values the fused kernel is built for
 inline bool shade_supported(int64_t C) { return C == 8 || C == 16 || C == 32 || C == 64; }
 

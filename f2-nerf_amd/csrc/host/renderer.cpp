@@ -331,15 +331,15 @@ f2n::TrainStepResult f2n::train_step(
 {
   RenderResult res =
     renderer.render(rays_o, rays_d, emb_idx, RunningMode::TRAIN, noise, bg_color);
-  Tensor err = res.colors - gt_colors;
-  Tensor color_loss = torch::sqrt(err.square() + 1e-4f).mean();
+  // colour loss + variance loss + squared error in two launches (f2n_loss_fwd; the ATen spelling of
+  // the reference, train_manager.cpp:78-96, is ~23 launches of a few microseconds each)
   Tensor var = CustomOps::WeightVar(res.weights, res.idx_start_end);
-  Tensor var_loss = (var + 1e-2f).sqrt().mean();
-  Tensor loss = color_loss + var_loss * var_loss_weight;
+  Tensor stats = f2n::train_loss(res.colors, gt_colors, var, var_loss_weight);  // {loss, c, v, sq}
+  Tensor loss = stats[0];
   TrainStepResult out;
   out.loss = loss.detach();
-  out.sq_err_sum = err.detach().square().sum();
-  out.n_values = err.numel();
+  out.sq_err_sum = stats[3].detach();
+  out.n_values = res.colors.numel();
   out.n_samples = renderer.last_n_samples_;
   if (run_backward && loss.requires_grad()) loss.backward();
   return out;

@@ -276,6 +276,17 @@ int f2n_adam_step(
   int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
   void * stream);
 
+/* The loss of the training iteration -- src/main_functions/train_manager.cpp:78-96:
+ *   color_loss = mean sqrt((colors - gt)^2 + 1e-4), var_loss = mean sqrt(var + 1e-2),
+ *   loss = color_loss + var_weight * var_loss, sq_err_sum = sum (colors - gt)^2 (PSNR, :95-96).
+ * colors, gt [n_rays, 3]; var [n_rays] (CustomOps::WeightVar).  Writes out4 = {loss, color_loss,
+ * var_loss, sq_err_sum} and the gradients of loss w.r.t. colors / var (closed forms; multiply by the
+ * upstream gradient).  partial: scratch of f2n_loss_workspace_floats(n_rays) floats.  Deterministic. */
+int64_t f2n_loss_workspace_floats(int n_rays);
+int f2n_loss_fwd(
+  const float * colors, const float * gt, const float * var, int n_rays, float var_weight,
+  float * d_colors, float * d_var, float * partial, float * out4, void * stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -150,3 +150,36 @@ def test_composite_fwd_bwd(capi, dev, n_rays, max_len, with_dw):
     torch.testing.assert_close(g_rgb.cpu(), rgb.grad, rtol=1e-4, atol=1e-6)
     ref = logit.grad
     torch.testing.assert_close(g_logit.cpu(), ref, rtol=1e-3, atol=1e-4 * ref.abs().max().item())
+
+
+@pytest.fixture(scope="module")
+def host():
+    import importlib
+    return importlib.import_module("f2-nerf_amd").load_host()
+
+
+@pytest.mark.parametrize("n_rays,weight", [(1, 0.0), (777, 1e-2), (70001, 0.3)])
+def test_train_loss_matches_aten_formula(host, dev, n_rays, weight):
+    """f2n::train_loss (two launches) against the reference's ATen spelling of the loss
+    (train_manager.cpp:78-96) with torch autograd for the gradients."""
+    g = torch.Generator().manual_seed(n_rays)
+    colors = torch.rand(n_rays, 3, generator=g).to(dev).requires_grad_(True)
+    gt = torch.rand(n_rays, 3, generator=g).to(dev)
+    var = (torch.rand(n_rays, generator=g) * 2).to(dev).requires_grad_(True)
+    stats = host.train_loss(colors, gt, var, weight)
+    c2 = colors.detach().clone().requires_grad_(True)
+    v2 = var.detach().clone().requires_grad_(True)
+    err = c2 - gt
+    color_loss = torch.sqrt(err.square() + 1e-4).mean()
+    var_loss = (v2 + 1e-2).sqrt().mean()
+    ref = color_loss + var_loss * weight
+    torch.testing.assert_close(stats[0], ref, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(stats[1], color_loss.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(stats[2], var_loss.detach(), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(stats[3], err.detach().square().sum(), rtol=1e-5, atol=1e-7)
+    (stats[0] * 3.0).backward()          # an upstream factor must reach both gradients
+    (ref * 3.0).backward()
+    torch.testing.assert_close(colors.grad, c2.grad, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(var.grad, v2.grad, rtol=1e-5, atol=1e-9)
+    again = host.train_loss(colors.detach(), gt, var.detach(), weight)
+    assert torch.equal(again, stats.detach())   # deterministic sums
