@@ -82,7 +82,10 @@ def _grad_worker(rank, world, port, out_q):
     loss.backward()
     grads = [w_big.grad, w_a.grad.t(), None, w_b.grad]      # a transposed view and a missing grad
     n_coll = sh.allreduce_gradients(grads, dist, small_bucket_bytes=1 << 16)
-    out_q.put((rank, n_coll, w_big.grad.clone(), w_a.grad.clone(), w_b.grad.clone()))
+    # plain numpy payloads: a torch tensor on a spawn Queue travels as a shared-memory handle that
+    # dies with the sender
+    out_q.put((rank, n_coll, w_big.grad.numpy().copy(), w_a.grad.numpy().copy(),
+               w_b.grad.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -115,7 +118,7 @@ def test_two_rank_gradient_average_matches_full_batch():
     (total / 2).backward()
     for r in res:
         assert r[1] == 2                                   # the table alone + one bucket
-        torch.testing.assert_close(r[2], w_big.grad, rtol=1e-6, atol=1e-7)
-        torch.testing.assert_close(r[3], w_a.grad, rtol=1e-6, atol=1e-7)
-        torch.testing.assert_close(r[4], w_b.grad, rtol=1e-6, atol=1e-7)
-    assert torch.equal(res[0][2], res[1][2])               # ranks agree bit for bit
+        torch.testing.assert_close(torch.from_numpy(r[2]), w_big.grad, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(torch.from_numpy(r[3]), w_a.grad, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(torch.from_numpy(r[4]), w_b.grad, rtol=1e-6, atol=1e-7)
+    assert (res[0][2] == res[1][2]).all()                  # ranks agree bit for bit
