@@ -7,9 +7,11 @@ Renderer::render(TRAIN) + loss + backward in 65 536-ray chunks (BASELINE.json co
 BASELINE.md.  Rays, step noise inputs (drawn on device per chunk, as the reference does), ground
 truth colours and all parameters are resident in HBM before the timed region starts.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): rays shard embarrassingly -- every rank
-renders its own view per step (weak scaling); the only collective is one RCCL all-reduce per step of
-{sum of squared error, value count} for the global PSNR.
+Multi-GPU: `python bench.py --gpus N` starts N ranks itself (child processes through
+torch.distributed.run, before this process touches the GPU); under an external launcher
+(RANK/LOCAL_RANK/WORLD_SIZE set) it is one of the ranks and WORLD_SIZE must equal --gpus.  Rays shard
+embarrassingly -- every rank renders its own view per step (weak scaling); the only collective is one
+RCCL all-reduce per step of {sum of squared error, value count} for the global PSNR.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     -- the dominant hand-written kernel's algorithmic bytes / its hipEvent-timed duration
@@ -53,6 +55,11 @@ def parse_args():
                     help="torch.distributed backend; nccl = RCCL (default). 'gloo' + --share-gpu lets "
                          "several ranks rehearse the multi-rank path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / collective check without a GPU: every rank joins the "
+                         "process group (use --backend gloo), shards a synthetic error vector, runs the "
+                         "path's one all-reduce and rank 0 prints a JSON line with n_gpus -- no kernels, "
+                         "no rays/s (tests/test_bench_launcher_cpu.py)")
     ap.add_argument("--rays", type=int, default=0,
                     help="rays per step per GPU instead of a full view (e.g. 512 = BASELINE config C4 "
                          "with --samples 1024); pixels drawn at random like dataset.cpp:153-155")
@@ -214,6 +221,35 @@ def cpu_baseline(args, n_rays):
                          max(1, len(times) - 1))}
 
 
+def dry_run(args, rank, world):
+    """The multi-rank skeleton of main() with the GPU work left out: process group, per-rank shard,
+    the {sum sq err, n} all-reduce, max-over-ranks timing, one JSON line on rank 0."""
+    pkg = importlib.import_module("f2-nerf_amd")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(2022)
+    err = torch.rand(4099, 3, generator=g, dtype=torch.float64)
+    lo, hi = pkg.sharding.shard_range(err.shape[0], rank, world)
+    t0 = time.perf_counter()
+    stat = pkg.sharding.reduce_error_stats(err[lo:hi].square().sum(), err[lo:hi].numel(), dist)
+    t_max = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "backend": args.backend if world > 1 else None,
+                          "views": [pkg.sharding.view_for(0, r, world, args.n_images) for r in range(world)],
+                          "sq_err_sum": float(stat[0]), "n_values": float(stat[1]),
+                          "want_sq_err_sum": float(err.square().sum()), "seconds": float(t_max)}),
+              flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def time_train_iterations(args, pkg, H, dev, dist, world, poses, intr):
     """K complete training iterations of the reference's batch (train_manager.cpp:66-107 minus
     logging): 512 rays per rank drawn on the device, S = 1024 / step 1/256, TRAIN render + loss +
@@ -255,13 +291,48 @@ def time_train_iterations(args, pkg, H, dev, dist, world, poses, intr):
                     "fwd + bwd + gradient all-reduce + fused Adam; not part of value"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as CHILD processes
+    through torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and return their exit code.
+    Called before anything touches the GPU: this process never initialises HIP, it only waits."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # decided before any torch.cuda call: the ranks are fresh child processes
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks"
+                         % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if not args.share_gpu and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py: %d ranks but only %d visible GPUs (use --share-gpu to rehearse)"
+                         % (world, torch.cuda.device_count()))
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)

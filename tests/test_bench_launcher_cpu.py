@@ -1,0 +1,67 @@
+"""bench.py's multi-rank launch path on CPU (gloo): `--gpus N` without a launcher must start N
+ranks as child processes and print ONE JSON line with n_gpus = N; under torch.distributed.run it
+must be one of the ranks; a WORLD_SIZE that disagrees with --gpus is an error, not a silent 1-rank
+run (VERDICT r1 item 1 / ADVICE bench.py:260)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def test_self_launch_two_ranks_gloo():
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--dry-run"],
+                         env=_env(), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = _json_lines(res.stdout)
+    assert len(lines) == 1, res.stdout            # rank 0 only
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["views"] == [0, 1]
+    assert d["n_values"] == 4099 * 3
+    assert abs(d["sq_err_sum"] - d["want_sq_err_sum"]) <= 1e-9 * d["want_sq_err_sum"]
+
+
+def test_under_external_launcher():
+    res = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), BENCH, "--gpus", "2", "--backend",
+         "gloo", "--dry-run"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = _json_lines(res.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+
+
+def test_world_size_mismatch_is_an_error():
+    env = _env()
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "WORLD_SIZE" in res.stderr
+
+
+def test_single_rank_dry_run_needs_no_launcher():
+    res = subprocess.run([sys.executable, BENCH, "--dry-run"], env=_env(), capture_output=True,
+                         text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert _json_lines(res.stdout)[0]["n_gpus"] == 1
