@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--chunk", type=int, default=65536)
     ap.add_argument("--regime", choices=["dense", "terminating"], default="dense")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rays", type=int, default=2048)
+    ap.add_argument("--cpu-rays", type=int, default=4096)
     ap.add_argument("--n-images", type=int, default=50)
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend; nccl = RCCL (default). 'gloo' + --share-gpu lets "
@@ -138,23 +138,47 @@ OP_KERNELS = {
 }
 
 
-def pmc_traffic_bytes(op):
-    """HBM-side bytes per launch of `op` from the newest committed rocprofv3 --pmc summary
-    (profiles/r*_pmc_traffic.json, made by tools/pmc_summary.py from separate FETCH_SIZE and
-    WRITE_SIZE passes of this same command; FETCH_SIZE doubled as the gfx950 guide prescribes).
-    PMC counters cannot be read inside the timed run, so this is a lookup, or None."""
+def kernels_sha16():
+    """Fingerprint of the kernel sources (the same function stamps a PMC summary when it is made):
+    a traffic figure is only quoted for the kernels it was measured on."""
+    import hashlib
+    kdir = os.path.join(ROOT, "f2-nerf_amd", "csrc", "kernels")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(kdir)):
+        if f.endswith((".hip", ".hiph")):
+            h.update(f.encode())
+            h.update(open(os.path.join(kdir, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(op, workload_key="c2"):
+    """(HBM-side bytes per launch of `op`, provenance) from the newest committed rocprofv3 --pmc
+    summary for this workload (profiles/r*_pmc_traffic*.json, made by tools/pmc_summary.py from
+    separate FETCH_SIZE and WRITE_SIZE passes of this same command; FETCH_SIZE doubled as the gfx950
+    guide prescribes).  PMC counters cannot be read inside the timed run, so this is a lookup; it is
+    refused (None, with the reason) when the summary was taken on other kernel sources."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
+    files = [f for f in files if (json.load(open(f)).get("_meta", {}).get("workload", "c2") == workload_key)]
     if not files:
-        return None
+        return None, {"file": None, "reason": "no PMC summary committed for this workload"}
+    src = {"file": os.path.relpath(files[-1], ROOT)}
     try:
         d = json.load(open(files[-1]))
+        meta = d.get("_meta", {})
+        src.update({k: meta.get(k) for k in ("kernels_sha16", "git_sha", "command") if meta.get(k)})
+        if meta.get("kernels_sha16") != kernels_sha16():
+            src["reason"] = ("stale: kernel sources changed since this summary was taken "
+                             "(now %s)" % kernels_sha16())
+            return None, src
         tot = 0.0
         for k in OP_KERNELS.get(op, []):
-            tot += d[k].get("read_bytes_corrected", 0.0) + d[k].get("write_bytes", 0.0)
-        return tot or None
-    except (KeyError, ValueError, OSError):
-        return None
+            if k in d:
+                tot += d[k].get("read_bytes_corrected", 0.0) + d[k].get("write_bytes", 0.0)
+        return (tot or None), src
+    except (KeyError, ValueError, OSError) as e:
+        src["reason"] = "unreadable: %r" % (e,)
+        return None, src
 
 
 def usable_cores():
@@ -177,6 +201,17 @@ def usable_cores():
         except (OSError, ValueError, IndexError):
             pass
     return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def cpu_baseline(args, n_rays):
@@ -203,22 +238,29 @@ def cpu_baseline(args, n_rays):
     o, d = R.get_rays_from_pose(poses[0:1], intr[None], ij)
     gt = torch.rand(n_rays, 3, generator=g)
     emb = torch.zeros(n_rays, dtype=torch.int32)
-    times = []
-    for it in range(3):
+    # BASELINE.md section 2 / SURVEY 8(d): median of >= 5 timed runs after 2 warm-ups, same seeded
+    # inputs shape as the GPU arm; bounded to ~1 minute of wall time whatever the host is
+    n_warm, n_timed, times = 2, 5, []
+    t_begin = time.perf_counter()
+    for it in range(n_warm + n_timed):
         noise = torch.rand(n_rays, args.samples, generator=g) + 0.5
         bg = torch.rand(n_rays, 3, generator=g)
         ren.zero_grad()
         t0 = time.perf_counter()
         loss, _, _, _ = R.train_loss(ren, o, d, emb, gt, noise, bg, 0.0)
         loss.backward()
-        times.append(time.perf_counter() - t0)
-        if sum(times) > 40:
+        if it >= n_warm:
+            times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_begin > 60 and len(times) >= 1:
             break
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": n_rays / best, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": "%d random rays of view 0, S=%d L=%d F=%d T=2^%d, fwd+bwd, best of %d after 1 warm-up"
+    times.sort()
+    med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
+    return {"value": n_rays / med, "unit": "rays/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "runs_s": [round(t, 4) for t in times],
+            "sample": "%d random rays of view 0, S=%d L=%d F=%d T=2^%d, fwd+bwd, median of %d timed "
+                      "runs after %d warm-ups"
                       % (n_rays, args.samples, args.levels, args.channels, args.log2_table,
-                         max(1, len(times) - 1))}
+                         len(times), n_warm)}
 
 
 def dry_run(args, rank, world):
@@ -475,8 +517,10 @@ def main():
         roofline = None
         if dom:
             a = kernels[dom]["achieved_GBs"]
+            traffic, traffic_src = pmc_traffic(dom)
             roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes(dom),
+                        "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": kernels[dom]["units_per_launch"] *
                         kernels[dom]["algorithmic_bytes_per_unit"],
                         "avg_launch_ms": kernels[dom]["avg_ms"]}

@@ -77,6 +77,39 @@ def lib():
     return _lib
 
 
+def option_keys(path=HEADER):
+    """{'SHADE_FWD': 0, ...} from the header's #define F2N_OPT_* lines."""
+    keys = {}
+    for m in re.finditer(r"#define\s+F2N_OPT_(\w+)\s+(\d+)", open(path).read()):
+        if m.group(1) != "COUNT":
+            keys[m.group(1)] = int(m.group(2))
+    return keys
+
+
+def set_option(name, value):
+    """f2n_set_option by name (e.g. set_option("SHADE_BWD", 1)); returns the previous value."""
+    L = lib()
+    prev = L.cdll.f2n_set_option(option_keys()[name.upper()], int(value))
+    if prev < 0:
+        raise F2NError("f2n_set_option(%s, %r) rejected" % (name, value))
+    return prev
+
+
+class option:
+    """Context manager: `with capi.option("HASH_BWD", 2): ...` restores the previous route on exit."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
+        return False
+
+
 def _ptr(x):
     if x is None:
         return None

@@ -10,7 +10,6 @@
 // table is one level (T*F*2 bytes: 2 MiB at the reference size), which an XCD's 4 MiB L2 holds.
 #include "hash_grid.hiph"
 
-#include <cstdlib>
 
 namespace
 {
@@ -700,8 +699,8 @@ extern "C" int f2n_hash_fwd_raytile(
   if (reinterpret_cast<uintptr_t>(table_f16) % (2u * F)) return F2N_E_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(out_cm) & 15u) return F2N_E_INVALID_ARG;
   if (n == 0) return F2N_OK;
-  const char * te = getenv("F2N_RAYTILE");  // samples per tile: 16 | 32 (measurements)
-  const int ts = (te && atoi(te) == 16) ? 16 : (S % 32 == 0 ? 32 : 16);
+  const int want = f2n_get_option(F2N_OPT_RAYTILE);  // samples per tile: 16 | 32 (measurements)
+  const int ts = (want == 16) ? 16 : (S % 32 == 0 ? 32 : 16);
   const int64_t tiles = (int64_t)f2n_div_up(n_rays, 64) * (S / ts);
   if (tiles > 0x7fffffff) return F2N_E_INVALID_ARG;
   const dim3 grid((unsigned)tiles, (unsigned)L), block(F2N_BLOCK);
@@ -747,9 +746,9 @@ extern "C" int f2n_hash_bwd(
   // repeated once per slice, so it only pays while the slice count stays moderate.
   const int64_t rows_per_slice = kSliceFloats / F;
   const int64_t n_slices = ((int64_t)T + rows_per_slice - 1) / rows_per_slice;
-  const char * force = getenv("F2N_HASH_BWD");  // "atomic" | "sliced": A/B switch for profiling
+  const int force = f2n_get_option(F2N_OPT_HASH_BWD);  // 1 atomic | 2 sliced: A/B switch
   bool sliced = !pts_grad && n_slices <= 64 && n >= 32768;
-  if (force && !pts_grad && n_slices <= 1024) sliced = (force[0] == 's');
+  if (force && !pts_grad && n_slices <= 1024) sliced = (force == 2);
   if (sliced) {
     // enough sample partitions to put >= 2 workgroups on every CU when levels x slices is small
     int n_parts = 1;

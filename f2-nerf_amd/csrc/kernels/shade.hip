@@ -498,10 +498,9 @@ extern "C" int f2n_shade_fwd(
   if (n == 0) return F2N_OK;
   if (!enc_cm || !dirs || !w_h || !b_h || !w1 || !b1 || !w2 || !b2 || !logit || !rgb)
     return F2N_E_INVALID_ARG;
-  // matrix-core forward (shade_mfma.hip) unless F2N_SHADE_FWD=vector asks for the one-sample-per-lane
+  // matrix-core forward (shade_mfma.hip) unless F2N_OPT_SHADE_FWD asks for the one-sample-per-lane
   // kernel below (A/B measurements) or n is beyond its 32-bit offsets
-  const char * froute = std::getenv("F2N_SHADE_FWD");
-  if (!(froute && std::strcmp(froute, "vector") == 0) && f2n_detail::shade_bwd_mfma_supports(64, n))
+  if (f2n_get_option(F2N_OPT_SHADE_FWD) == 0 && f2n_detail::shade_bwd_mfma_supports(64, n))
     return f2n_detail::launch_shade_fwd_mfma(
       enc_cm, C, dirs, sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, logit, rgb, pre_cm, n,
       (hipStream_t)stream);
@@ -527,9 +526,8 @@ extern "C" int f2n_shade_bwd(
     return F2N_E_INVALID_ARG;
   if (app_emb && sample_img && !g_app_emb) return F2N_E_INVALID_ARG;
   // matrix-core kernel (shade_mfma.hip) unless the saved pre-activations are offered, the width has
-  // no MFMA tiling, or F2N_SHADE_BWD=valu asks for the vector kernel (A/B measurements)
-  const char * route = std::getenv("F2N_SHADE_BWD");
-  const bool force_valu = route && std::strcmp(route, "valu") == 0;
+  // no MFMA tiling, or F2N_OPT_SHADE_BWD asks for the vector kernel (A/B measurements)
+  const bool force_valu = f2n_get_option(F2N_OPT_SHADE_BWD) == 1;
   if (!force_valu && !pre_cm && f2n_detail::shade_bwd_mfma_supports(C, n))
     return f2n_detail::launch_shade_bwd_mfma(
       enc_cm, C, dirs, sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, d_logit, d_rgb, d_enc_cm,

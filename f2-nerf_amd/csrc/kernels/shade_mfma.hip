@@ -797,8 +797,7 @@ int launch_shade_bwd_mfma(
   // the embedding rows are read as float4
   if (app_emb && (reinterpret_cast<uintptr_t>(app_emb) & 15u)) return F2N_E_INVALID_ARG;
   if ((int64_t)C * n >= ((int64_t)1 << 30)) return F2N_E_UNSUPPORTED;  // 32-bit byte offsets
-  const char * ve = std::getenv("F2N_SHADE_VARIANT");
-  const int variant = ve ? std::atoi(ve) : 0;
+  const int variant = f2n_get_option(F2N_OPT_SHADE_VARIANT);
 #define F2N_LAUNCH_MFMA_V(CC, VV)                                                                    \
   {                                                                                                  \
     constexpr int kW = MShape<CC>::kWaves;                                                             \

@@ -11,7 +11,9 @@
  * Conventions (inherited from the reference's launch sites):
  *   - all pointers are DEVICE pointers to contiguous, caller-owned, caller-allocated buffers;
  *   - no entry point allocates, frees, synchronises or keeps state between calls (calls arrive
- *     from the forward thread and from the autograd engine's device thread);
+ *     from the forward thread and from the autograd engine's device thread); the one exception is
+ *     the explicit, process-wide kernel-route table of f2n_set_option below (atomics; defaults =
+ *     the production routes; nothing is read from the environment);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *   - return value: F2N_OK (0) or a negative F2N_E_* code; nothing throws;
  *   - counts are elements, never bytes; `idx`/`bounds` are [n_rays, 2] int32 {start, end}.
@@ -36,6 +38,21 @@ extern "C" {
 
 int f2n_abi_version(void);
 const char * f2n_status_string(int status);
+
+/* Kernel-route switches for A/B measurements and for tests that must cover every route.  They
+ * select between implementations of the SAME operation (results agree within the documented bars);
+ * value 0 is always the production default.  Process-wide, lock-free (relaxed atomics): safe to
+ * call while other threads launch, takes effect for launches issued afterwards.
+ * f2n_set_option returns the previous value, or F2N_E_INVALID_ARG for an unknown key / value. */
+#define F2N_OPT_SHADE_FWD 0     /* 0 matrix-core forward, 1 one-sample-per-lane vector kernel       */
+#define F2N_OPT_SHADE_BWD 1     /* 0 matrix-core backward, 1 vector (VALU + LDS) backward           */
+#define F2N_OPT_SHADE_VARIANT 2 /* 0 phase-fenced matrix-core backward, 1 unfenced                  */
+#define F2N_OPT_RAYTILE 3       /* samples per ray tile of f2n_hash_fwd_raytile: 0 auto, 16, 32     */
+#define F2N_OPT_HASH_BWD 4      /* f2n_hash_bwd route: 0 auto, 1 global atomics, 2 LDS-sliced       */
+#define F2N_OPT_BWD_COMBINE 5   /* binned backward: 0 combine coarse levels per tile, 1 never       */
+#define F2N_OPT_COUNT 6
+int f2n_set_option(int key, int value);
+int f2n_get_option(int key);
 
 /* ------------------------------------------------------------------ hash grid (rows A1, A2) --- */
 

@@ -30,3 +30,13 @@ def dev():
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a GPU: the HIP path has no CPU fallback")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _default_kernel_routes():
+    """Every test starts and ends on the production kernel routes (f2n_set_option is process-wide)."""
+    yield
+    capi = importlib.import_module("f2-nerf_amd").capi
+    if capi._lib is not None:
+        for name in capi.option_keys():
+            capi.set_option(name, 0)

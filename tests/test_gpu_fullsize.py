@@ -82,11 +82,10 @@ def test_hash_fwd_bwd_properties(capi, dev, field):
     outs["binned"] = tg
     del ws
     for mode in ("sliced", "atomic"):
-        os.environ["F2N_HASH_BWD"] = mode
-        tg = torch.zeros(numel, device=dev)
-        capi.call("hash_bwd", x, *args, g, 1, N, tg, None, N, L, F, T, T, 128.0)
+        with capi.option("HASH_BWD", {"atomic": 1, "sliced": 2}[mode]):
+            tg = torch.zeros(numel, device=dev)
+            capi.call("hash_bwd", x, *args, g, 1, N, tg, None, N, L, F, T, T, 128.0)
         outs[mode] = tg
-    os.environ.pop("F2N_HASH_BWD", None)
     scale = float(outs["binned"].abs().max())
     for mode in ("sliced", "atomic"):
         assert float((outs[mode] - outs["binned"]).abs().max()) <= 2e-5 * scale, mode

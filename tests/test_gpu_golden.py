@@ -116,13 +116,13 @@ def test_raytile_and_rays_against_golden(capi, dev):
     torch.testing.assert_close(dd.cpu(), r["rays_d"], rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("fwd_route,bwd_route", [("mfma", "auto"), ("vector", "valu")])
-def test_shade_network_against_golden(capi, dev, monkeypatch, fwd_route, bwd_route):
+@pytest.mark.parametrize("fwd_route,bwd_route", [(0, 0), (1, 1)], ids=["matrix-core", "vector"])
+def test_shade_network_against_golden(capi, dev, fwd_route, bwd_route):
     """f2n_shade_fwd / f2n_shade_bwd (matrix-core and vector kernels) against the stored outputs and
     gradients of the op-by-op network."""
     z = _load("shade_network")
-    monkeypatch.setenv("F2N_SHADE_FWD", fwd_route)
-    monkeypatch.setenv("F2N_SHADE_BWD", bwd_route)
+    capi.set_option("SHADE_FWD", fwd_route)
+    capi.set_option("SHADE_BWD", bwd_route)
     n, C = z["enc"].shape
     dv = lambda t: t.to(dev).contiguous()
     enc_cm = dv(z["enc"].t())

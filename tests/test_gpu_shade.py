@@ -29,7 +29,7 @@ def _reference(enc, dirs, img, P, d_logit, d_rgb):
 @pytest.mark.parametrize("C,n,with_emb", [(32, 5000, True), (32, 64 * 9 + 17, False), (8, 3000, True),
                                           (64, 2000, True), (16, 1, True), (16, 777, False),
                                           (32, 64 * 2100 + 5, True)])
-def test_shade_fwd_bwd(capi, dev, monkeypatch, C, n, with_emb):
+def test_shade_fwd_bwd(capi, dev, C, n, with_emb):
     g = torch.Generator().manual_seed(C + n)
     E = 5
     enc = (torch.randn(n, C, generator=g) * 0.1).to(torch.float16).float()
@@ -53,10 +53,10 @@ def test_shade_fwd_bwd(capi, dev, monkeypatch, C, n, with_emb):
     logit = torch.empty(n, device=dev)
     rgb = torch.empty(n, 3, device=dev)
     pre_cm = torch.empty(64, n, device=dev)
-    # forward: the vector kernel (default) and the matrix-core kernel (F2N_SHADE_FWD=mfma)
+    # forward: the matrix-core kernel (default) and the vector kernel (F2N_OPT_SHADE_FWD = 1)
     pre_first = None
     for froute in ("mfma", "vector"):
-        monkeypatch.setenv("F2N_SHADE_FWD", froute)
+        capi.set_option("SHADE_FWD", 1 if froute == "vector" else 0)
         logit.fill_(7.0)
         rgb.fill_(7.0)
         pre_cm.fill_(7.0)
@@ -68,7 +68,7 @@ def test_shade_fwd_bwd(capi, dev, monkeypatch, C, n, with_emb):
             pre_first = pre_cm.clone()
         else:   # the hidden pre-activations the two kernels hand to a backward agree
             torch.testing.assert_close(pre_cm, pre_first, rtol=1e-4, atol=1e-5)
-    monkeypatch.delenv("F2N_SHADE_FWD")
+    capi.set_option("SHADE_FWD", 0)
 
     # three routes to the same gradients: the matrix-core kernel (default where it has a tiling:
     # C in 8/16/32/64), the vector kernel recomputing the forward, and the vector kernel fed with the
@@ -79,7 +79,7 @@ def test_shade_fwd_bwd(capi, dev, monkeypatch, C, n, with_emb):
                   G["b1"], G["w2"], G["b2"], G["emb"] if with_emb else None, pre, n)
 
     for route in ("default", "valu", "valu_saved_pre"):
-        monkeypatch.setenv("F2N_SHADE_BWD", "valu" if route != "default" else "auto")
+        capi.set_option("SHADE_BWD", 1 if route != "default" else 0)
         d_enc = torch.full((C, n), 7.0, device=dev)      # must be overwritten
         G = {k: torch.zeros_like(v) for k, v in Pd.items()}
         run_bwd(G, d_enc, pre_cm if route == "valu_saved_pre" else None)

@@ -110,7 +110,7 @@ def main():
     grad_cm = grad_rm.t().contiguous()
     tg = torch.zeros(numel, device=dev)
     for mode in ("atomic", "sliced"):
-        os.environ["F2N_HASH_BWD"] = mode
+        capi.set_option("HASH_BWD", {"atomic": 1, "sliced": 2}[mode])
         for name, gr, ldp, ldc in (("row-major", grad_rm, C, 1), ("chan-major", grad_cm, 1, n)):
             try:
                 med, best = timeit(lambda: capi.call("hash_bwd", pts, table16, primes, bias, mul, gr, ldp, ldc,
@@ -119,7 +119,7 @@ def main():
                       (mode, name, med, best, n * bytes_fwd / med / 1e6))
             except Exception as e:
                 print("  bwd %s %s: %s" % (mode, name, e))
-    os.environ.pop("F2N_HASH_BWD", None)
+    capi.set_option("HASH_BWD", 0)
     need = capi.lib().cdll.f2n_hash_bwd_workspace_bytes(n, L, F, T)
     if need > 0:
         ws = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -30,15 +30,16 @@ def t(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 pre = torch.empty(64, n, device=dev)
 print("fwd matrix-core (default) %.3f ms" % t(lambda: capi.call("shade_fwd", enc, C, dirs, img, *P, emb, logit, rgb, None, n)))
-os.environ["F2N_SHADE_FWD"] = "vector"
+capi.set_option("SHADE_FWD", 1)
 print("fwd vector                %.3f ms" % t(lambda: capi.call("shade_fwd", enc, C, dirs, img, *P, emb, logit, rgb, None, n)))
-os.environ.pop("F2N_SHADE_FWD")
+capi.set_option("SHADE_FWD", 0)
 print("fwd + save pre %.3f ms" % t(lambda: capi.call("shade_fwd", enc, C, dirs, img, *P, emb, logit, rgb, pre, n)))
 bwd = lambda pre_: capi.call("shade_bwd", enc, C, dirs, img, *P, emb, dl, dr, denc, *G, pre_, n)
-os.environ["F2N_SHADE_BWD"] = "auto"
+capi.set_option("SHADE_BWD", 0)
 for v in (0, 1):
-    os.environ["F2N_SHADE_VARIANT"] = str(v)
+    capi.set_option("SHADE_VARIANT", v)
     print("bwd matrix-core variant %d  %.3f ms" % (v, t(lambda: bwd(None))))
-os.environ["F2N_SHADE_BWD"] = "valu"
+capi.set_option("SHADE_VARIANT", 0)
+capi.set_option("SHADE_BWD", 1)
 print("bwd vector, recompute      %.3f ms" % t(lambda: bwd(None)))
 print("bwd vector, saved pre      %.3f ms" % t(lambda: bwd(pre)))

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection.csv files per kernel (average per dispatch).
 
-  python tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/rNN_pmc.json
+  python tools/pmc_summary.py [--workload c2] [--command "..."] gpurun_out/pmc_fetch gpurun_out/pmc_write \
+      > profiles/rNN_pmc_traffic.json
+
+The summary is stamped (`_meta`) with a fingerprint of the kernel sources it was measured on, so
+bench.py quotes `roofline.traffic` only while the kernels are unchanged.
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
 (MI355X_MICROARCH.md, HBM section): `read_bytes_corrected` applies that factor; gather-dominated
@@ -24,7 +28,16 @@ def short(name):
     return None
 
 
-def main(dirs):
+def main(argv):
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--command", default="")
+    ap.add_argument("dirs", nargs="+")
+    a = ap.parse_args(argv)
+    dirs = a.dirs
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for d in dirs:
         for f in glob.glob(d + "/*/*counter_collection.csv"):
@@ -49,6 +62,9 @@ def main(dirs):
         if "WRITE_SIZE_avg" in e:
             e["write_bytes"] = e["WRITE_SIZE_avg"] * 1024
         out[k] = e
+    from bench import kernels_sha16
+    out["_meta"] = {"workload": a.workload, "kernels_sha16": kernels_sha16(), "command": a.command,
+                    "git_sha": os.environ.get("F2N_GIT_SHA", "")}
     json.dump(out, sys.stdout, indent=1)
     print()
 
