@@ -55,6 +55,9 @@ def parse_args():
                     help="torch.distributed backend; nccl = RCCL (default). 'gloo' + --share-gpu lets "
                          "several ranks rehearse the multi-rank path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="kernel route for A/B measurements (f2n_set_option), e.g. BWD_COMBINE=1; "
+                         "recorded in the JSON line")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / collective check without a GPU: every rank joins the "
                          "process group (use --backend gloo), shards a synthetic error vector, runs the "
@@ -132,7 +135,8 @@ OP_KERNELS = {
     "hash_fwd": ["hash_fwd_kernel", "hash_fwd_raytile_kernel"],
     "shade_fwd": ["shade_fwd_kernel"],
     "shade_bwd": ["shade_bwd_mfma_kernel", "shade_bwd_kernel"],
-    "hash_bwd": ["hash_bwd_bin_kernel", "hash_bwd_reduce_kernel"],
+    "hash_bwd": ["hash_bwd_bin_kernel", "hash_bwd_split_kernel", "hash_bwd_reduce_kernel",
+                 "hash_bwd_reduce_runs_kernel"],
     "density_march": ["density_march_kernel"],
     "density_scan": ["density_scan_kernel"],
 }
@@ -387,6 +391,9 @@ def main():
 
     pkg = importlib.import_module("f2-nerf_amd")
     H = pkg.load_host()
+    for kv in args.option:
+        name, value = kv.split("=")
+        pkg.capi.set_option(name, int(value))
     H.manual_seed(2022)          # reference main.cpp:11; identical parameters on every rank
     torch.manual_seed(2022)
     S, L, F = args.samples, args.levels, args.channels
@@ -538,6 +545,7 @@ def main():
                        "regime": args.regime, "rays_per_step_per_gpu": n_rays_view,
                        "samples_per_ray_kept": n_samples_total / (n_rays_view * args.steps),
                        "sharding": "one view per rank per step, RCCL all-reduce of {sq_err, n} only"},
+            "kernel_options": args.option,
             "psnr_vs_random_gt": psnr,
             "optimizer_step_ms": {"fused_adam_with_f16_shadow": opt_ms["make_fused_adam"],
                                   "torch_optim_adam": opt_ms["make_adam"],

@@ -7,6 +7,8 @@
 
 #include <cmath>
 
+#include <hip/hip_runtime_api.h>
+
 using Tensor = torch::Tensor;
 
 TORCH_LIBRARY(dec_hash3d_anchored, m)
@@ -290,22 +292,39 @@ variable_list Hash3DAnchoredFunction::backward(AutogradContext * ctx, variable_l
   Tensor embeds_grad = torch::zeros_like(feat_pool);
   void * stream = f2n::current_stream(points);
   // Large training batches: bin the contributions by table slice into a scratch workspace and
-  // reduce them in LDS (no scattered atomics; exact, order-independent sums).  288 GB of HBM make
-  // the ~2 bytes-per-algorithmic-byte workspace a non-issue; the caching allocator recycles it.
-  const int64_t ws_bytes =
+  // reduce them in LDS (no scattered atomics; exact, order-independent sums).  The recommended
+  // workspace is about 3 bytes per algorithmic byte (16 GiB for 8.4 M samples at L = 16, F = 2,
+  // capped at 24 GiB: bigger batches run in rounds); it is further capped at half of the device's
+  // free memory, and when even that cannot be allocated the atomic kernel takes over.
+  int64_t ws_bytes =
     want_points ? 0 : f2n_hash_bwd_workspace_bytes(n, L, F, (uint32_t)field->local_size_);
+  Tensor ws;
   if (ws_bytes > 0 && field->options_.binned_backward) {
-    Tensor ws = torch::empty({ws_bytes}, points.options().dtype(torch::kUInt8));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      // memory held by the caching allocator is reusable too: only cap when the device is tight
+      const int64_t cap = (int64_t)(free_b / 2);
+      if (cap < ws_bytes && cap >= ws_bytes / 16) ws_bytes = cap / 256 * 256;
+    }
+    try {
+      ws = torch::empty({ws_bytes}, points.options().dtype(torch::kUInt8));
+    } catch (const c10::Error &) {
+      ws = Tensor();  // out of memory: fall through to the kernel that needs no workspace
+    }
+  }
+  bool done = false;
+  if (ws.defined()) {
     f2n::ScopedKernelTimer timer("hash_bwd", stream, (double)n);
-    f2n::check(
-      f2n_hash_bwd_binned(
-        points.data_ptr<float>(), field->prim_pool_.data_ptr<int32_t>(),
-        field->bias_pool_.data_ptr<float>(), field->level_mul_.data_ptr<float>(),
-        grad_in.data_ptr<float>(), ld_point, ld_chan, embeds_grad.data_ptr<float>(), n, L, F,
-        (uint32_t)field->local_size_, field->level_stride_, grad_scale, ws.data_ptr(), ws_bytes,
-        stream),
-      "f2n_hash_bwd_binned");
-  } else {
+    const int st = f2n_hash_bwd_binned(
+      points.data_ptr<float>(), field->prim_pool_.data_ptr<int32_t>(),
+      field->bias_pool_.data_ptr<float>(), field->level_mul_.data_ptr<float>(),
+      grad_in.data_ptr<float>(), ld_point, ld_chan, embeds_grad.data_ptr<float>(), n, L, F,
+      (uint32_t)field->local_size_, field->level_stride_, grad_scale, ws.data_ptr(), ws_bytes,
+      stream);
+    if (st != F2N_E_UNSUPPORTED) f2n::check(st, "f2n_hash_bwd_binned");
+    done = (st == F2N_OK);  // unsupported = the (shrunk) workspace holds not even one tile
+  }
+  if (!done) {
     f2n::ScopedKernelTimer timer("hash_bwd", stream, (double)n);
     f2n::check(
       f2n_hash_bwd(

@@ -1,0 +1,1070 @@
+// hash_bwd_binned.hip -- table gradient of the hash-grid encode without scattered atomics
+// (replaces Hash3DAnchoredBackwardKernel's half2 atomics,
+// reference src/hash_3d_anchored.cu:95-145,181-218, for training-sized batches).
+//
+// Every contribution is f16(f16(scale*g) * w_d) per channel, exactly as the reference forms it, i.e.
+// an integer multiple of 2^-24 below 2^16.  The pipeline moves those contributions as RECORDS
+// {row, F halves} to the workgroup that owns the row and sums them EXACTLY in 64-bit fixed point
+// (ds_add_u64: LDS integer atomics run 12x faster than float ones on gfx950), so the table gradient
+// does not depend on summation order.  A "slice" is the range of table rows whose accumulators fit
+// one workgroup's LDS: kBinAcc / F rows (128 KiB of 64-bit sums).
+//
+//   pass A (bin)     one 1024-thread workgroup per tile of 1024 points walks all levels; records are
+//                    staged per BUCKET in 128 KiB of LDS queues and leave as contiguous regions of the
+//                    workspace.  Up to 64 slices per level a bucket IS a slice.  Coarse levels, where
+//                    the points of a tile share cells, are first COMBINED per tile: a direct-mapped
+//                    LDS table keyed by row (tag, then add: no compare-and-swap loop) sums equal-row
+//                    contributions exactly, and only the sums leave, re-expressed as f16 pieces so the
+//                    record format does not change.
+//   pass B (split)   only when a level has more than 64 slices (T*F > 2^20, e.g. T = 2^22, F = 8:
+//                    2048 slices): a bucket is 2^k slices; pass B streams a bucket's regions and
+//                    splits them by slice through LDS queues into long per-slice runs.
+//   pass C (reduce)  one workgroup per (level, slice): stream the slice's regions / runs, ds_add_u64,
+//                    then add the slice into the table gradient with contiguous float atomics (the
+//                    reference's level windows overlap, quirk Q2, so it must be an add).
+//
+// Capacities never affect results: a record that finds its queue or region full is applied directly
+// with global float atomics (order-dependent in the last bit, like the reference's own atomics).
+#include "hash_grid.hiph"
+
+#include <algorithm>
+#include <atomic>
+
+namespace
+{
+
+constexpr int kBinBlock = 1024;        // threads = points per tile (pass A), threads of pass C
+constexpr int kBinAcc = 16384;         // 64-bit accumulators per slice (128 KiB)
+constexpr int kBinQueueWords = 32768;  // 128 KiB of LDS record staging per tile (pass A)
+constexpr int kCombAccWords = 8192 + 16;  // combine mode: 4096 (+ pitch padding) 64-bit sums, M = 4096 / F slots
+constexpr int kCombTagWords = 4096;    //               M row tags (sized for F = 1)
+constexpr int kCombQueueWords = kBinQueueWords - kCombAccWords - kCombTagWords;  // 80 KiB stay a queue
+constexpr int kMaxPieces = 6;          // f16 pieces per combined sum before the remainder goes atomic
+// A combined level costs about twice a plain one (two ds_add_u64 per contribution, 4-way same-address
+// inside a wave at the coarsest levels), so it must shrink the record stream a lot to pay:
+constexpr int kCombineMinRunQ8 = 5 * 256;  // mean samples per level-0-scaled cell along a ray (x256)
+constexpr int kCombinePaysAt = 4500;       // ... or records saved per tile-level, predicted
+constexpr int kCombineDenseTile = 6000;    // level 0 is tried when the tile has this many non-zero
+                                           // contributions (of 8192): that is where plain binning
+                                           // overflows its queues at the coarse levels
+constexpr int kSplitBlock = 512;       // pass B: two workgroups per CU
+constexpr int kSplitQueueWords = 16384;  // 64 KiB
+constexpr int kSplitRegions = 4;       // regions a wave of pass B ingests per round
+constexpr int kMaxBuckets = 64;
+constexpr int kMaxLog2Sub = 6;
+
+// Record of F channels: word 0 = row inside the bucket, then the F halves packed two per word.
+// F <= 2: array of {row, value} pairs (8 bytes).  F >= 4: structure of arrays inside each region
+// (all rows, then all value groups of 8 / 16 bytes) so both parts move as full-width vector accesses.
+template <int F>
+struct Rec
+{
+  static constexpr int kValWords = (F >= 2 ? F / 2 : 1);
+  static constexpr int kWords = 1 + kValWords;
+  static constexpr bool kSoA = (F >= 4);
+};
+
+// f16 bits -> value * 2^24 as a signed 64-bit integer (exact for every finite f16)
+__device__ __forceinline__ long long f16_bits_to_fixed(uint32_t hbits)
+{
+  const uint32_t e = (hbits >> 10) & 31u, m = hbits & 0x3ffu;
+  const unsigned long long mag =
+    e ? ((unsigned long long)(0x400u | m) << (e - 1u)) : (unsigned long long)m;
+  return (hbits & 0x8000u) ? -(long long)mag : (long long)mag;
+}
+
+__device__ __forceinline__ bool f16_bits_nonfinite(uint32_t hbits) { return (hbits & 0x7c00u) == 0x7c00u; }
+
+// Largest-magnitude f16 (towards zero) of a fixed-point sum; subtracts it from S.  Repeated calls
+// re-express any |S| < 2^63 as f16 values whose exact sum is S (11 bits per piece).
+__device__ __forceinline__ uint32_t take_f16_piece(long long & S)
+{
+  if (S == 0) return 0u;
+  const bool neg = S < 0;
+  const unsigned long long mag = neg ? (unsigned long long)(-S) : (unsigned long long)S;
+  const int hb = 63 - __clzll((long long)mag);
+  unsigned long long piece;
+  uint32_t bits;
+  if (hb >= 40) {  // beyond the f16 range: peel off 65504 at a time
+    piece = 2047ull << 29;
+    bits = 0x7bffu;
+  } else {
+    const int shift = hb > 10 ? hb - 10 : 0;
+    const unsigned long long m = mag >> shift;  // 11 significant bits
+    piece = m << shift;
+    bits = (uint32_t)((shift << 10) + (int)m);  // exponent field = shift + 1 once bit 10 of m is set
+  }
+  S = neg ? S + (long long)piece : S - (long long)piece;
+  return bits | (neg ? 0x8000u : 0u);
+}
+
+template <int F>
+__device__ __forceinline__ uint32_t val_channel_bits(const uint32_t * val, int k)
+{
+  const uint32_t word = val[F >= 2 ? k / 2 : 0];
+  return (k & 1) ? (word >> 16) : (word & 0xffffu);
+}
+
+// One record straight into the table gradient (queue / region full, non-finite halves).
+template <int F>
+__device__ __forceinline__ void apply_record_atomic(
+  float * __restrict__ gbase, uint32_t row, const uint32_t * val, float inv_scale)
+{
+#pragma unroll
+  for (int k = 0; k < F; k++) {
+    const float v = h2f((uint16_t)val_channel_bits<F>(val, k));
+    if (v != 0.f) atomicAdd(gbase + (int64_t)row * F + k, v * inv_scale);
+  }
+}
+
+template <int F>
+__device__ __forceinline__ bool val_all_zero(const uint32_t * val)
+{
+  uint32_t any = 0u;
+#pragma unroll
+  for (int j = 0; j < Rec<F>::kValWords; j++) any |= val[j];
+  return (any & 0x7fff7fffu) == 0u;
+}
+
+// LDS / workspace addressing of record `slot` of a region with capacity `cap` starting at `base`.
+template <int F>
+__device__ __forceinline__ void store_record(uint32_t * base, int cap, uint32_t slot, uint32_t row, const uint32_t * val)
+{
+  constexpr int VW = Rec<F>::kValWords;
+  if constexpr (!Rec<F>::kSoA) {
+    *reinterpret_cast<uint2 *>(base + (size_t)slot * 2) = make_uint2(row, val[0]);
+  } else {
+    base[slot] = row;
+    uint32_t * v = base + cap + (size_t)slot * VW;
+    if constexpr (VW == 2) *reinterpret_cast<uint2 *>(v) = make_uint2(val[0], val[1]);
+    else *reinterpret_cast<uint4 *>(v) = make_uint4(val[0], val[1], val[2], val[3]);
+  }
+}
+
+template <int F>
+__device__ __forceinline__ void load_record(const uint32_t * base, int cap, uint32_t slot, uint32_t & row, uint32_t * val)
+{
+  constexpr int VW = Rec<F>::kValWords;
+  if constexpr (!Rec<F>::kSoA) {
+    const uint2 r = *reinterpret_cast<const uint2 *>(base + (size_t)slot * 2);
+    row = r.x;
+    val[0] = r.y;
+  } else {
+    row = base[slot];
+    const uint32_t * v = base + cap + (size_t)slot * VW;
+    if constexpr (VW == 2) {
+      const uint2 r = *reinterpret_cast<const uint2 *>(v);
+      val[0] = r.x;
+      val[1] = r.y;
+    } else {
+      const uint4 r = *reinterpret_cast<const uint4 *>(v);
+      val[0] = r.x;
+      val[1] = r.y;
+      val[2] = r.z;
+      val[3] = r.w;
+    }
+  }
+}
+
+// Copy the first `cnt` records of an LDS queue (capacity src_cap) into a workspace region (capacity
+// dst_cap, records dst_off..) with the 64 lanes of one wave.
+template <int F>
+__device__ __forceinline__ void copy_records(
+  const uint32_t * src, int src_cap, uint32_t * dst, int dst_cap, uint32_t dst_off, uint32_t cnt, int lane)
+{
+  constexpr int VW = Rec<F>::kValWords;
+  if constexpr (!Rec<F>::kSoA) {
+    const uint2 * s = reinterpret_cast<const uint2 *>(src);
+    uint2 * d = reinterpret_cast<uint2 *>(dst) + dst_off;
+    for (uint32_t i = lane; i < cnt; i += 64) d[i] = s[i];
+  } else {
+    for (uint32_t i = lane; i < cnt; i += 64) dst[dst_off + i] = src[i];
+    if constexpr (VW == 2) {
+      const uint2 * s = reinterpret_cast<const uint2 *>(src + src_cap);
+      uint2 * d = reinterpret_cast<uint2 *>(dst + dst_cap) + dst_off;
+      for (uint32_t i = lane; i < cnt; i += 64) d[i] = s[i];
+    } else {
+      const uint4 * s = reinterpret_cast<const uint4 *>(src + src_cap);
+      uint4 * d = reinterpret_cast<uint4 *>(dst + dst_cap) + dst_off;
+      for (uint32_t i = lane; i < cnt; i += 64) d[i] = s[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------ pass A: bin ----
+
+// scalars of pass A (pointers stay plain __restrict__ kernel arguments: wave-uniform loads through
+// them are then scalar loads)
+struct BinArgs
+{
+  int64_t g_ld_point, g_ld_chan;
+  int64_t n;        // points of this chunk (pts / grad_out already point at its first point)
+  int64_t n_tiles;  // tiles of this chunk
+  int64_t level_stride;
+  uint32_t T;
+  int L;
+  float grad_scale, inv_scale;
+  int n_buckets, bshift, groups, qcap, qcap_comb, combine;
+  uint32_t * stats;  // optional [L][4] u32 counters (tools/ab_hash_bwd.py), else NULL
+};
+
+template <int F, bool POW2>
+__global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
+  const float * __restrict__ pts, const int32_t * __restrict__ primes,
+  const float * __restrict__ bias, const float * __restrict__ mul,
+  const float * __restrict__ grad_out, float * __restrict__ table_grad,
+  uint32_t * __restrict__ ws_records, uint32_t * __restrict__ ws_counts, const BinArgs a)
+{
+  constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
+  constexpr uint32_t kSlots = 4096 / F;  // combine table: slots (tags), F 64-bit sums each
+  // channel-major with an odd pitch, for the same bank reason as SliceAcc (F >= 2: 4096 + F words)
+  auto comb_index = [](uint32_t slot, int k) { return (uint32_t)k * (kSlots + (F > 1 ? 1u : 0u)) + slot; };
+  __shared__ __attribute__((aligned(16))) uint32_t queue[kBinQueueWords];
+  __shared__ uint32_t qcount[kMaxBuckets];
+  // [0] combine the coming level, [1] non-zero contributions of this level, [2] lanes of the tile
+  // whose level-0 cell equals the previous sample's, [3] lanes that have a previous sample,
+  // [4] mean run length at level 0 (x256), [5] records that overflowed this level
+  __shared__ uint32_t comb_state[6];
+  unsigned long long * const comb_acc =
+    reinterpret_cast<unsigned long long *>(queue + kBinQueueWords - kCombAccWords);
+  uint32_t * const comb_tag = queue + kBinQueueWords - kCombAccWords - kCombTagWords;
+
+  // One workgroup owns a tile of points for ALL levels: the point is read once, and the gradient
+  // channels of level l+1 are requested before level l is processed -- with a 128 KiB LDS stage only
+  // one workgroup fits a CU, so nothing else would hide that load.
+  const int64_t tile = blockIdx.x;
+  const int64_t p = tile * kBinBlock + threadIdx.x;
+  const bool valid = p < a.n;
+  const int64_t pc = valid ? p : a.n - 1;
+  const float x = pts[3 * pc + 0], y = pts[3 * pc + 1], z = pts[3 * pc + 2];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  constexpr int kWaves = kBinBlock / 64;
+  const uint32_t bmask = (1u << a.bshift) - 1u;
+  const int64_t n_tiles_g = a.n_tiles * a.groups;
+
+  float g_cur[F], g_nxt[F];
+#pragma unroll
+  for (int k = 0; k < F; k++) g_cur[k] = grad_out[pc * a.g_ld_point + (int64_t)k * a.g_ld_chan];
+
+  const bool comb_allowed = a.combine && a.groups == 1;
+  if (threadIdx.x < 6) comb_state[threadIdx.x] = 0u;
+  __syncthreads();
+  if (comb_allowed) {
+    // how many consecutive samples share a level-0 cell?  (points are ray-major: the lanes of a wave
+    // are consecutive samples of a ray.)  Dense sampling (the reference's 1024 steps of 1/256: 32
+    // per cell) makes long runs of identical rows: that is where combining pays and where plain
+    // binning overflows its queues.
+    const LevelParams lp0 = load_level(primes, bias, mul, 0);
+    const int cx = (int)floorf(fmaf(x, lp0.mul, lp0.bx)), cy = (int)floorf(fmaf(y, lp0.mul, lp0.by)),
+              cz = (int)floorf(fmaf(z, lp0.mul, lp0.bz));
+    const int px = dpp_get_i<0x138, 0xf, 0xf>(cx), py = dpp_get_i<0x138, 0xf, 0xf>(cy),
+              pz = dpp_get_i<0x138, 0xf, 0xf>(cz);
+    const bool has_prev = valid && lane > 0;
+    const unsigned long long m_prev = __ballot(has_prev);
+    const unsigned long long m_same = __ballot(has_prev && cx == px && cy == py && cz == pz);
+    // ... and how many of the tile's 8192 level-0 contributions are non-zero?  (Gradients of
+    // samples that barely contribute underflow the f16 scale and are never binned.)
+    uint32_t n_nz0 = 0u;
+    {
+      bool any0 = false;
+      float gk0[F];
+#pragma unroll
+      for (int k = 0; k < F; k++) {
+        gk0[k] = round_f16(g_cur[k] * a.grad_scale);
+        any0 |= (gk0[k] != 0.f);
+      }
+      if (valid && any0) {
+        uint32_t row0[8];
+        float w0[8];
+        corner_rows_and_weights<POW2>(x, y, z, lp0, a.T, row0, w0);
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+          bool nz = false;
+#pragma unroll
+          for (int k = 0; k < F; k++) {
+            float c = gk0[k] * w0[d];
+            asm volatile("" : "+v"(c));
+            nz |= (__half_as_ushort(__float2half_rn(c)) & 0x7fffu) != 0;
+          }
+          n_nz0 += nz ? 1u : 0u;
+        }
+      }
+    }
+    const uint32_t nz_wave = (uint32_t)__builtin_amdgcn_readlane(wave_incl_scan_i32((int)n_nz0), 63);
+    if (lane == 0) {
+      atomicAdd(&comb_state[2], (uint32_t)__popcll(m_same));
+      atomicAdd(&comb_state[3], (uint32_t)__popcll(m_prev));
+      atomicAdd(&comb_state[1], nz_wave);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t breaks = comb_state[3] - comb_state[2] + (uint32_t)kWaves;  // runs in the tile
+      const uint32_t run_q8 = (uint32_t)(((uint64_t)(comb_state[3] + kWaves) << 8) / breaks);
+      comb_state[4] = run_q8;
+      comb_state[0] =
+        (run_q8 >= (uint32_t)kCombineMinRunQ8 || comb_state[1] >= (uint32_t)kCombineDenseTile) ? 1u : 0u;
+      if (a.stats) {
+        atomicAdd(a.stats + 3, comb_state[1]);
+        atomicAdd(a.stats + 7, 1u);
+      }
+    }
+  }
+
+
+  for (int l = 0; l < a.L; l++) {
+    {
+      const int ln = (l + 1 < a.L) ? l + 1 : l;  // clamped: the last prefetch re-reads level L-1
+#pragma unroll
+      for (int k = 0; k < F; k++)
+        g_nxt[k] = grad_out[pc * a.g_ld_point + (int64_t)(ln * F + k) * a.g_ld_chan];
+    }
+    float gk[F];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < F; k++) {
+      gk[k] = round_f16(g_cur[k] * a.grad_scale);
+      any |= (gk[k] != 0.f);
+    }
+    const bool active = valid && any;  // the reference skips all-zero channel groups (:133)
+    uint32_t row[8];
+    float w[8];
+    float * gbase = table_grad + a.level_stride * l;
+
+    // contribution of corner d as packed halves
+    auto corner_value = [&](int d, uint32_t * val) {
+      if constexpr (F == 1) {
+        float c0 = gk[0] * w[d];
+        asm volatile("" : "+v"(c0));  // keep the f32 rounding before the f16 one (see round_f16)
+        val[0] = (uint32_t)__half_as_ushort(__float2half_rn(c0));
+      } else {
+#pragma unroll
+        for (int k = 0; k < F; k += 2) {
+          float c0 = gk[k] * w[d], c1 = gk[k + 1] * w[d];
+          asm volatile("" : "+v"(c0), "+v"(c1));
+          val[k / 2] = (uint32_t)__half_as_ushort(__float2half_rn(c0)) |
+                       ((uint32_t)__half_as_ushort(__float2half_rn(c1)) << 16);
+        }
+      }
+    };
+    // stage one record in its bucket's LDS queue (layout capacity `cap`), or apply it directly
+    auto enqueue = [&](uint32_t r, const uint32_t * val, int cap) {
+      const uint32_t bucket = r >> a.bshift;
+      const uint32_t slot = atomicAdd(&qcount[bucket], 1u);
+      if (slot < (uint32_t)cap)
+        store_record<F>(queue + (size_t)bucket * cap * KW, cap, slot, r & bmask, val);
+      else
+        apply_record_atomic<F>(gbase, r, val, a.inv_scale);
+    };
+    // wave w copies the queues of buckets w, w+16, ... to their workspace regions and records the
+    // counts ([level][bucket][tile] so that pass B / C read them coalesced)
+    auto flush = [&](int cap, int64_t tile_g) {
+      uint32_t * region0 =
+        ws_records + ((size_t)l * n_tiles_g + tile_g) * a.n_buckets * (size_t)a.qcap * KW;
+      if constexpr (!Rec<F>::kSoA) {
+        // the LDS reads of up to four buckets are issued before the first store
+        for (int b0 = wave; b0 < a.n_buckets; b0 += 4 * kWaves) {
+          uint2 v[4][4];
+          uint32_t cnt[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int b = b0 + u * kWaves;
+            cnt[u] = b < a.n_buckets ? min(qcount[b], (uint32_t)cap) : 0u;
+            const uint2 * q = reinterpret_cast<const uint2 *>(queue + (size_t)b * cap * KW);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if ((uint32_t)(lane + 64 * k) < cnt[u]) v[u][k] = q[lane + 64 * k];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int b = b0 + u * kWaves;
+            uint2 * dst = reinterpret_cast<uint2 *>(region0 + (size_t)b * a.qcap * KW);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if ((uint32_t)(lane + 64 * k) < cnt[u]) dst[lane + 64 * k] = v[u][k];
+            for (uint32_t i = lane + 256; i < cnt[u]; i += 64)  // capacities above 256 (few buckets)
+              dst[i] = reinterpret_cast<const uint2 *>(queue + (size_t)b * cap * KW)[i];
+          }
+        }
+      } else {
+        for (int b = wave; b < a.n_buckets; b += kWaves) {
+          const uint32_t cnt = min(qcount[b], (uint32_t)cap);
+          copy_records<F>(
+            queue + (size_t)b * cap * KW, cap, region0 + (size_t)b * a.qcap * KW, a.qcap, 0u, cnt, lane);
+        }
+      }
+      if ((int)threadIdx.x < a.n_buckets)
+        ws_counts[((size_t)l * a.n_buckets + threadIdx.x) * n_tiles_g + tile_g] =
+          min(qcount[threadIdx.x], (uint32_t)cap);
+    };
+
+    __syncthreads();  // the previous level's flush has read the queues and counters
+    const bool comb = comb_state[0] != 0u;
+    if (threadIdx.x < kMaxBuckets) qcount[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) comb_state[1] = 0u;
+    __syncthreads();
+
+    if (comb) {
+      // ---- combine: equal rows of this tile are summed in LDS before they become records --------
+      {  // zero the sums (32 KiB); tags need no reset: a slot is only read after a write of this level
+        uint4 * zp = reinterpret_cast<uint4 *>(comb_acc);
+        zp[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        zp[threadIdx.x + kBinBlock] = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x < kCombAccWords / 4 - 2 * kBinBlock)
+          zp[threadIdx.x + 2 * kBinBlock] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      if (active) {
+        const LevelParams lp = load_level(primes, bias, mul, l);
+        corner_rows_and_weights<POW2>(x, y, z, lp, a.T, row, w);
+#pragma unroll
+        for (int d = 0; d < 8; d++) comb_tag[row[d] & (kSlots - 1u)] = row[d];  // some writer wins
+      }
+      __syncthreads();
+      uint32_t n_nz = 0u;
+      if (active) {
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+          uint32_t val[VW];
+          corner_value(d, val);
+          if (val_all_zero<F>(val)) continue;
+          n_nz++;
+          const uint32_t slot = row[d] & (kSlots - 1u);
+          bool finite = true;
+#pragma unroll
+          for (int k = 0; k < F; k++) finite &= !f16_bits_nonfinite(val_channel_bits<F>(val, k));
+          if (comb_tag[slot] == row[d] && finite) {
+#pragma unroll
+            for (int k = 0; k < F; k++) {
+              const uint32_t hb = val_channel_bits<F>(val, k);
+              if (hb & 0x7fffu)
+                atomicAdd(&comb_acc[comb_index(slot, k)], (unsigned long long)f16_bits_to_fixed(hb));
+            }
+          } else {
+            enqueue(row[d], val, a.qcap_comb);  // lost the slot to another row: an ordinary record
+          }
+        }
+      }
+      {
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane(wave_incl_scan_i32((int)n_nz), 63);
+        if (lane == 0 && tot) atomicAdd(&comb_state[1], tot);
+      }
+      __syncthreads();
+      // emit the sums as f16 pieces (same record format, exact)
+      for (uint32_t s = threadIdx.x; s < kSlots; s += kBinBlock) {
+        long long S[F];
+        bool nz = false;
+#pragma unroll
+        for (int k = 0; k < F; k++) {
+          S[k] = (long long)comb_acc[comb_index(s, k)];
+          nz |= (S[k] != 0);
+        }
+        if (!nz) continue;
+        const uint32_t r = comb_tag[s];
+        for (int piece = 0; piece < kMaxPieces && nz; piece++) {
+          uint32_t val[VW];
+#pragma unroll
+          for (int j = 0; j < VW; j++) val[j] = 0u;
+          nz = false;
+#pragma unroll
+          for (int k = 0; k < F; k++) {
+            const uint32_t hb = take_f16_piece(S[k]);
+            val[F >= 2 ? k / 2 : 0] |= (k & 1) ? (hb << 16) : hb;
+            nz |= (S[k] != 0);
+          }
+          enqueue(r, val, a.qcap_comb);
+        }
+        if (nz) {  // sums beyond kMaxPieces * 11 bits (near the f16 overflow): the rest goes direct
+#pragma unroll
+          for (int k = 0; k < F; k++)
+            if (S[k] != 0)
+              atomicAdd(
+                gbase + (int64_t)r * F + k,
+                (float)((double)S[k] * ((double)a.inv_scale * (1.0 / 16777216.0))));
+        }
+      }
+      __syncthreads();
+      flush(a.qcap_comb, tile);
+      // Combine the next level too?  Yes while the sampling is still dense relative to its cells, or
+      // while the records saved (measured here, scaled by the ~1.6x more distinct rows a finer level
+      // has) outweigh the cost of the mode.  Finer levels only get worse: once off, it stays off.
+      if (wave == 0) {
+        uint32_t e = (lane < a.n_buckets) ? qcount[lane] : 0u;
+        e = (uint32_t)__builtin_amdgcn_readlane(wave_incl_scan_i32((int)e), 63);
+        if (lane == 0) {
+          const uint32_t n_nz_tile = comb_state[1];
+          if (a.stats) {
+            atomicAdd(a.stats + 4 * l + 0, 1u);
+            atomicAdd(a.stats + 4 * l + 1, n_nz_tile);
+            atomicAdd(a.stats + 4 * l + 2, e);
+          }
+          const int ln = (l + 1 < a.L) ? l + 1 : l;
+          const float run_next = (float)comb_state[4] * (mul[0] / mul[ln]);
+          const bool dense = run_next >= (float)kCombineMinRunQ8;
+          const bool pays = (float)n_nz_tile - 1.6f * (float)e >= (float)kCombinePaysAt;
+          if (!(dense || pays)) comb_state[0] = 0u;
+        }
+      }
+    } else {
+      // ---- plain binning: one record per (point, corner).  When the queues cannot hold a whole
+      // tile-level (F = 8 with 64 buckets) the tile's points take turns in `groups` rounds.
+      for (int g = 0; g < a.groups; g++) {
+        if (g > 0) {
+          __syncthreads();  // the previous round's flush has read the queues
+          if (threadIdx.x < kMaxBuckets) qcount[threadIdx.x] = 0u;
+          __syncthreads();
+        }
+        if (active && (int)((threadIdx.x * (unsigned)a.groups) / kBinBlock) == g) {
+          const LevelParams lp = load_level(primes, bias, mul, l);
+          corner_rows_and_weights<POW2>(x, y, z, lp, a.T, row, w);
+#pragma unroll
+          for (int d = 0; d < 8; d++) {
+            uint32_t val[VW];
+            corner_value(d, val);
+            if (val_all_zero<F>(val)) continue;
+            enqueue(row[d], val, a.qcap);
+          }
+        }
+        __syncthreads();
+        flush(a.qcap, tile * a.groups + g);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < F; k++) g_cur[k] = g_nxt[k];
+  }
+}
+
+// ------------------------------------------------------------------------------ pass B: split --
+
+struct SplitArgs
+{
+  const uint32_t * a_records;
+  const uint32_t * a_counts;
+  uint32_t * b_records;
+  uint32_t * b_counts;
+  float * table_grad;
+  int64_t level_stride;
+  int64_t n_tiles_g;  // regions per (level, bucket) of pass A
+  float inv_scale;
+  int n_buckets, bshift, log2_sub, qcap, n_slices, tiles_per_part, n_parts, cap2;
+};
+
+template <int F>
+__global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const SplitArgs a)
+{
+  constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
+  constexpr uint32_t kRows = kBinAcc / F;
+  constexpr int kWaves = kSplitBlock / 64;
+  __shared__ __attribute__((aligned(16))) uint32_t queue[kSplitQueueWords];
+  __shared__ uint32_t qcount[64], cursor[64];
+  const int bucket = blockIdx.x, l = blockIdx.y, part = blockIdx.z;
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int n_sub = 1 << a.log2_sub;
+  const int Q = (kSplitQueueWords / (n_sub * KW)) & ~3;  // records per sub-slice queue
+  const int64_t t_begin = (int64_t)part * a.tiles_per_part;
+  const int64_t t_end = min(t_begin + (int64_t)a.tiles_per_part, a.n_tiles_g);
+  const uint32_t * counts = a.a_counts + ((size_t)l * a.n_buckets + bucket) * a.n_tiles_g;
+  const size_t tile_stride = (size_t)a.n_buckets * a.qcap * KW;
+  const uint32_t * base = a.a_records + ((size_t)l * a.n_tiles_g * a.n_buckets + bucket) * (size_t)a.qcap * KW;
+  float * gbase = a.table_grad + a.level_stride * l;
+  const uint32_t row0 = (uint32_t)bucket << a.bshift;
+  const int n_half = (a.qcap + 63) / 64;
+
+  if (threadIdx.x < 64) {
+    qcount[threadIdx.x] = 0u;
+    cursor[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+
+  for (int64_t t0 = t_begin; t0 < t_end; t0 += (int64_t)kWaves * kSplitRegions) {
+    // ingest: this wave's regions of the round, all loads issued before the first LDS push
+    uint32_t cnt[kSplitRegions];
+#pragma unroll
+    for (int u = 0; u < kSplitRegions; u++) {
+      const int64_t t = t0 + (int64_t)wave * kSplitRegions + u;
+      cnt[u] = (t < t_end) ? counts[t] : 0u;
+    }
+    for (int h = 0; h < n_half; h++) {
+      uint32_t r[kSplitRegions], v[kSplitRegions][VW];
+#pragma unroll
+      for (int u = 0; u < kSplitRegions; u++) {
+        const int64_t t = t0 + (int64_t)wave * kSplitRegions + u;
+        const uint32_t last = cnt[u] ? cnt[u] - 1u : 0u;
+        const uint32_t i = min((uint32_t)(lane + 64 * h), last);  // branch-free: tail lanes re-read
+        const uint32_t * region = base + (size_t)((t < t_end) ? t : t_begin) * tile_stride;
+        load_record<F>(region, a.qcap, i, r[u], v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kSplitRegions; u++) {
+        if ((uint32_t)(lane + 64 * h) < cnt[u]) {
+          const uint32_t sub = r[u] / kRows, local = r[u] & (kRows - 1u);
+          const uint32_t slot = atomicAdd(&qcount[sub], 1u);
+          if (slot < (uint32_t)Q)
+            store_record<F>(queue + (size_t)sub * Q * KW, Q, slot, local, v[u]);
+          else
+            apply_record_atomic<F>(gbase, row0 + r[u], v[u], a.inv_scale);
+        }
+      }
+    }
+    __syncthreads();
+    // append every queue to its slice's run of this part
+    for (int sub = wave; sub < n_sub; sub += kWaves) {
+      const uint32_t c = min(qcount[sub], (uint32_t)Q), cur = cursor[sub];
+      const uint32_t fit = min(c, (uint32_t)a.cap2 - cur);
+      const int slice = (bucket << a.log2_sub) + sub;
+      if (slice < a.n_slices) {
+        uint32_t * run = a.b_records + (((size_t)l * a.n_slices + slice) * a.n_parts + part) * (size_t)a.cap2 * KW;
+        copy_records<F>(queue + (size_t)sub * Q * KW, Q, run, a.cap2, cur, fit, lane);
+        for (uint32_t i = fit + lane; i < c; i += 64) {  // run full: apply directly
+          uint32_t rr, vv[VW];
+          load_record<F>(queue + (size_t)sub * Q * KW, Q, i, rr, vv);
+          apply_record_atomic<F>(gbase, row0 + (uint32_t)sub * kRows + rr, vv, a.inv_scale);
+        }
+      }
+      if (lane == 0) {
+        cursor[sub] = cur + fit;
+        qcount[sub] = 0u;
+      }
+    }
+    __syncthreads();
+  }
+  if ((int)threadIdx.x < n_sub) {
+    const int slice = (bucket << a.log2_sub) + threadIdx.x;
+    if (slice < a.n_slices)
+      a.b_counts[((size_t)l * a.n_slices + slice) * a.n_parts + part] = cursor[threadIdx.x];
+  }
+}
+
+// ------------------------------------------------------------------------------ pass C: reduce -
+
+constexpr int kRegionsInFlight = 8;  // regions a wave loads before it accumulates them
+
+// Non-finite contributions (an incoming gradient beyond the f16 range) cannot enter the fixed-point
+// sums; they are remembered per accumulator as three bit sets {+inf, -inf, NaN} and folded in when
+// the slice is flushed: the row ends up inf / NaN exactly where the reference's f16 sums would.
+constexpr int kPoisonWords = kBinAcc / 32;
+
+// The sums are kept CHANNEL-major with an odd row pitch: sum[k * (rows + 1) + row].  Row-major
+// (row * F + k) would put the 64 lanes of one ds_add_u64 -- random rows, one channel -- on only
+// 64 / (2 F) distinct bank pairs (4 at F = 8: a 16-way bank conflict on every accumulate).
+constexpr int kSumWords = kBinAcc + 8;
+
+struct SliceAcc
+{
+  unsigned long long sum[kSumWords];
+  uint32_t poison[3][kPoisonWords];
+};
+
+template <int F>
+__device__ __forceinline__ uint32_t sum_index(uint32_t local_row, int k)
+{
+  return (uint32_t)k * (uint32_t)(kBinAcc / F + 1) + local_row;
+}
+
+__device__ __forceinline__ void zero_slice(SliceAcc & sa)
+{
+  for (int i = threadIdx.x; i < kSumWords; i += kBinBlock) sa.sum[i] = 0ull;
+  for (int i = threadIdx.x; i < 3 * kPoisonWords; i += kBinBlock) (&sa.poison[0][0])[i] = 0u;
+}
+
+template <int F>
+__device__ __forceinline__ void accumulate_record(SliceAcc & sa, uint32_t local_row, const uint32_t * val)
+{
+#pragma unroll
+  for (int k = 0; k < F; k++) {
+    const uint32_t hb = val_channel_bits<F>(val, k);
+    const uint32_t i = local_row * F + k;
+    if (f16_bits_nonfinite(hb)) {
+      const int which = (hb & 0x3ffu) ? 2 : ((hb & 0x8000u) ? 1 : 0);
+      atomicOr(&sa.poison[which][i >> 5], 1u << (i & 31u));
+    } else if (hb & 0x7fffu) {
+      atomicAdd(&sa.sum[sum_index<F>(local_row, k)], (unsigned long long)f16_bits_to_fixed(hb));
+    }
+  }
+}
+
+// Add the slice into the table gradient: contiguous float atomics in general (the reference's level
+// windows overlap, quirk Q2, so two slices may own the same element), plain read-modify-write when
+// the caller's level stride keeps the windows apart (DISJOINT).
+template <int F, bool DISJOINT>
+__device__ __forceinline__ void flush_slice(
+  const SliceAcc & sa, float * gbase_slice, uint32_t row_lo, uint32_t T, float inv_scale)
+{
+  constexpr uint32_t kRows = kBinAcc / F;
+  const uint32_t rows_here = (row_lo + kRows <= T) ? kRows : (T > row_lo ? T - row_lo : 0u);
+  const int n_flush = (int)rows_here * F;
+  const double unit = (double)inv_scale * (1.0 / 16777216.0);
+  constexpr int kBatch = 8;  // DISJOINT: the batch's loads are all in flight before the first store
+  for (int i0 = threadIdx.x; i0 < n_flush; i0 += kBinBlock * kBatch) {
+    float add[kBatch], old[kBatch];
+    bool live[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; u++) {
+      const int i = i0 + u * kBinBlock;
+      live[u] = false;
+      add[u] = 0.f;
+      old[u] = 0.f;
+      if (i < n_flush) {
+        const long long v = (long long)sa.sum[sum_index<F>((uint32_t)i / F, i % F)];
+        const uint32_t bit = 1u << (i & 31);
+        const bool pinf = sa.poison[0][i >> 5] & bit, ninf = sa.poison[1][i >> 5] & bit,
+                   nan = sa.poison[2][i >> 5] & bit;
+        add[u] = (float)((double)v * unit);
+        if (nan || (pinf && ninf)) add[u] = __builtin_nanf("");
+        else if (pinf) add[u] = __builtin_inff();
+        else if (ninf) add[u] = -__builtin_inff();
+        live[u] = (v != 0 || pinf || ninf || nan);
+        if (DISJOINT && live[u]) old[u] = gbase_slice[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; u++) {
+      const int i = i0 + u * kBinBlock;
+      if (live[u]) {
+        if (DISJOINT) gbase_slice[i] = old[u] + add[u];
+        else atomicAdd(gbase_slice + i, add[u]);
+      }
+    }
+  }
+}
+
+// single-level: the regions pass A wrote for (level, slice = bucket), one per tile
+template <int F, bool DISJOINT>
+__global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
+  const uint32_t * __restrict__ ws_records, const uint32_t * __restrict__ ws_counts,
+  float * __restrict__ table_grad, uint32_t T, int64_t level_stride, float inv_scale, int n_slices,
+  int qcap, int64_t n_tiles)
+{
+  constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
+  constexpr uint32_t kRows = kBinAcc / F;
+  constexpr int kWaves = kBinBlock / 64;
+  __shared__ SliceAcc acc;
+  const int sidx = blockIdx.x, l = blockIdx.y;
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  zero_slice(acc);
+  __syncthreads();
+
+  const uint32_t row_lo = (uint32_t)sidx * kRows;
+  float * gbase_slice = table_grad + level_stride * l + (int64_t)row_lo * F;
+  const uint32_t * counts = ws_counts + ((size_t)l * n_slices + sidx) * n_tiles;
+  const size_t tile_stride = (size_t)n_slices * qcap * KW;  // words between tiles, same slice
+  const uint32_t * base = ws_records + ((size_t)l * n_tiles * n_slices + sidx) * (size_t)qcap * KW;
+  const int n_half = (qcap + 63) / 64;  // 64-lane loads per region
+  // a wave owns 64 consecutive tiles at a time: one coalesced load fetches their counts, then the
+  // regions are read several tiles at a time so that many loads are in flight per lane
+  for (int64_t t0 = (int64_t)wave * 64; t0 < n_tiles; t0 += (int64_t)kWaves * 64) {
+    const uint32_t my_cnt = (t0 + lane < n_tiles) ? counts[t0 + lane] : 0u;
+    const int n_here = (int)min((int64_t)64, n_tiles - t0);
+    for (int j0 = 0; j0 < n_here; j0 += kRegionsInFlight) {
+      uint32_t cnt[kRegionsInFlight];
+      uint32_t cnt_max = 0u;
+#pragma unroll
+      for (int u = 0; u < kRegionsInFlight; u++) {
+        cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (j0 + u) & 63);
+        if ((j0 + u) >= n_here) cnt[u] = 0u;
+        cnt_max = max(cnt_max, cnt[u]);
+      }
+      for (int h = 0; h < n_half && (uint32_t)(64 * h) < cnt_max; h++) {  // wave-uniform bound
+        uint32_t r[kRegionsInFlight], v[kRegionsInFlight][VW];
+#pragma unroll
+        for (int u = 0; u < kRegionsInFlight; u++) {
+          const bool live = (j0 + u) < n_here;
+          const uint32_t * region = base + (size_t)(t0 + (live ? j0 + u : 0)) * tile_stride;
+          // branch-free load so the loads are in flight together: lanes past the region's count
+          // re-read its last record (same cache lines, no extra traffic) and skip it below
+          const uint32_t last = cnt[u] ? cnt[u] - 1u : 0u;
+          const uint32_t i = min((uint32_t)(lane + 64 * h), last);
+          load_record<F>(region, qcap, i, r[u], v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kRegionsInFlight; u++)
+          if ((uint32_t)(lane + 64 * h) < cnt[u])
+            accumulate_record<F>(acc, r[u], v[u]);
+      }
+    }
+  }
+  __syncthreads();
+  flush_slice<F, DISJOINT>(acc, gbase_slice, row_lo, T, inv_scale);
+}
+
+// two-level: the runs pass B wrote for (level, slice), one per part
+template <int F, bool DISJOINT>
+__global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_runs_kernel(
+  const uint32_t * __restrict__ b_records, const uint32_t * __restrict__ b_counts,
+  float * __restrict__ table_grad, uint32_t T, int64_t level_stride, float inv_scale, int n_slices,
+  int n_parts, int cap2)
+{
+  constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
+  constexpr uint32_t kRows = kBinAcc / F;
+  constexpr int kWaves = kBinBlock / 64;
+  constexpr int kUnroll = 8;
+  __shared__ SliceAcc acc;
+  const int sidx = blockIdx.x, l = blockIdx.y;
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  zero_slice(acc);
+  __syncthreads();
+
+  const uint32_t row_lo = (uint32_t)sidx * kRows;
+  float * gbase_slice = table_grad + level_stride * l + (int64_t)row_lo * F;
+  for (int part = wave; part < n_parts; part += kWaves) {
+    const size_t ridx = ((size_t)l * n_slices + sidx) * n_parts + part;
+    const uint32_t cnt = min(b_counts[ridx], (uint32_t)cap2);
+    const uint32_t * run = b_records + ridx * (size_t)cap2 * KW;
+    for (uint32_t i0 = 0; i0 < cnt; i0 += 64 * kUnroll) {
+      uint32_t r[kUnroll], v[kUnroll][VW];
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) {
+        const uint32_t i = min(i0 + 64 * u + lane, cnt - 1u);
+        load_record<F>(run, cap2, i, r[u], v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++)
+        if (i0 + 64 * u + lane < cnt) accumulate_record<F>(acc, r[u], v[u]);
+    }
+  }
+  __syncthreads();
+  flush_slice<F, DISJOINT>(acc, gbase_slice, row_lo, T, inv_scale);
+}
+
+// ------------------------------------------------------------------------------ planning -------
+
+struct BinPlan
+{
+  bool ok = false;
+  int n_slices = 0, n_buckets = 0, log2_sub = 0, bshift = 0, groups = 1, qcap = 0, qcap_comb = 0;
+  int64_t chunk_tiles = 0;  // tiles processed per round of the three passes
+  // per-chunk layout (for chunk_tiles tiles)
+  int tiles_per_part = 0, n_parts = 0, cap2 = 0;
+  int64_t a_counts_bytes = 0, a_records_bytes = 0, b_counts_bytes = 0, b_records_bytes = 0;
+  int64_t bytes = 0;
+};
+
+int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+int ilog2(uint32_t v)
+{
+  int r = 0;
+  while ((1u << r) < v) r++;
+  return r;
+}
+
+// layout of the workspace for `tiles` tiles under the capacities already chosen in pl
+void layout_for(BinPlan & pl, int L, int F, int64_t tiles)
+{
+  const int kw = 1 + (F >= 2 ? F / 2 : 1);
+  const int64_t tiles_g = tiles * pl.groups;
+  pl.a_counts_bytes = align256((int64_t)L * pl.n_buckets * tiles_g * 4);
+  pl.a_records_bytes = align256((int64_t)L * tiles_g * pl.n_buckets * pl.qcap * kw * 4);
+  pl.b_counts_bytes = pl.b_records_bytes = 0;
+  pl.tiles_per_part = pl.n_parts = pl.cap2 = 0;
+  if (pl.log2_sub > 0) {
+    // parts: about 32 per (level, bucket), whole multiples of the 8 x kSplitRegions regions a
+    // round of pass B ingests
+    const int round = (kSplitBlock / 64) * kSplitRegions;
+    int64_t tpp = (tiles_g + 31) / 32;
+    tpp = std::max<int64_t>((tpp + round - 1) / round * round, 2 * round);
+    pl.tiles_per_part = (int)tpp;
+    pl.n_parts = (int)((tiles_g + tpp - 1) / tpp);
+    const double mean_region = 8.0 * kBinBlock / pl.groups / pl.n_buckets;
+    const double mean_run = mean_region * (double)tpp / (double)(1 << pl.log2_sub);
+    pl.cap2 = ((int)(mean_run * 1.5) + 128 + 3) & ~3;
+    pl.b_counts_bytes = align256((int64_t)L * pl.n_slices * pl.n_parts * 4);
+    pl.b_records_bytes = align256((int64_t)L * pl.n_slices * pl.n_parts * pl.cap2 * kw * 4);
+  }
+  pl.bytes = pl.a_counts_bytes + pl.a_records_bytes + pl.b_counts_bytes + pl.b_records_bytes;
+}
+
+// Capacities of the binned backward for (n, L, F, T); !ok means "not applicable".  workspace_bytes
+// > 0: shrink the number of tiles handled per round until the layout fits.
+BinPlan bin_plan(int64_t n, int L, int F, uint32_t T, int64_t workspace_bytes)
+{
+  BinPlan pl;
+  if (!(F == 1 || F == 2 || F == 4 || F == 8) || L < 1 || n < 65536) return pl;
+  const int kw = 1 + (F >= 2 ? F / 2 : 1);
+  const int64_t rows_per_slice = kBinAcc / F;
+  const int64_t n_slices = ((int64_t)T + rows_per_slice - 1) / rows_per_slice;
+  int s = 0;
+  while (((n_slices + (1 << s) - 1) >> s) > kMaxBuckets) s++;
+  if (s > kMaxLog2Sub) return pl;
+  pl.n_slices = (int)n_slices;
+  pl.log2_sub = s;
+  pl.n_buckets = (int)((n_slices + (1 << s) - 1) >> s);
+  pl.bshift = ilog2((uint32_t)rows_per_slice) + s;
+  // corner groups: the queues of one round (8/groups corners of 1024 points) must fit the LDS stage
+  // with 25 % slack over the mean region size
+  for (int groups = 1; groups <= 8; groups *= 2) {
+    const int avg = (8 * kBinBlock / groups + pl.n_buckets - 1) / pl.n_buckets;
+    const int cap = std::min(2 * avg, kBinQueueWords / (pl.n_buckets * kw)) & ~3;
+    if (cap >= avg + avg / 4) {
+      pl.groups = groups;
+      pl.qcap = cap;
+      break;
+    }
+  }
+  if (pl.qcap == 0) return pl;
+  pl.qcap_comb = std::min(pl.qcap, kCombQueueWords / (pl.n_buckets * kw)) & ~3;
+  const int64_t total_tiles = (n + kBinBlock - 1) / kBinBlock;
+  int64_t tiles = total_tiles;
+  layout_for(pl, L, F, tiles);
+  if (workspace_bytes > 0 && pl.bytes > workspace_bytes) {
+    // bytes grow (almost) linearly with the tile count: estimate, then step down until it fits
+    tiles = std::max<int64_t>(1, (int64_t)((double)tiles * (double)workspace_bytes / (double)pl.bytes));
+    for (;;) {
+      layout_for(pl, L, F, tiles);
+      if (pl.bytes <= workspace_bytes || tiles == 1) break;
+      tiles = std::max<int64_t>(1, tiles - std::max<int64_t>(1, tiles / 16));
+    }
+    if (pl.bytes > workspace_bytes) return pl;  // not even one tile fits
+  }
+  pl.chunk_tiles = tiles;
+  pl.ok = true;
+  return pl;
+}
+
+constexpr int64_t kRecommendedWorkspaceCap = (int64_t)48 << 30;
+
+std::atomic<uint32_t *> g_bin_stats{nullptr};
+
+inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1u)); }
+
+}  // namespace
+
+// Measurement hook of tools/ab_hash_bwd.py (not part of the ABI header): a device buffer of
+// [F2N_MAX_LEVELS][4] u32 that pass A fills with {tiles that combined the level, their non-zero
+// contributions, the records they emitted, 0}; NULL switches it off.
+extern "C" void f2n_debug_bin_stats(uint32_t * device_counters)
+{
+  g_bin_stats.store(device_counters, std::memory_order_relaxed);
+}
+
+extern "C" int64_t f2n_hash_bwd_workspace_bytes(int64_t n, int L, int F, uint32_t T)
+{
+  BinPlan pl = bin_plan(n, L, F, T, 0);
+  if (!pl.ok) return 0;
+  if (pl.bytes <= kRecommendedWorkspaceCap) return pl.bytes;
+  pl = bin_plan(n, L, F, T, kRecommendedWorkspaceCap);  // bigger batches run in several rounds
+  return pl.ok ? pl.bytes : 0;
+}
+
+#define F2N_DISPATCH_F(F_, ...)      \
+  switch (F_) {                      \
+    case 1: { constexpr int FF = 1; __VA_ARGS__; } break; \
+    case 2: { constexpr int FF = 2; __VA_ARGS__; } break; \
+    case 4: { constexpr int FF = 4; __VA_ARGS__; } break; \
+    case 8: { constexpr int FF = 8; __VA_ARGS__; } break; \
+    default: return F2N_E_UNSUPPORTED; \
+  }
+
+extern "C" int f2n_hash_bwd_binned(
+  const float * pts, const int32_t * primes, const float * bias, const float * mul,
+  const float * grad_out, int64_t g_ld_point, int64_t g_ld_chan, float * table_grad, int64_t n,
+  int L, int F, uint32_t T, int64_t level_stride, float grad_scale, void * workspace,
+  int64_t workspace_bytes, void * stream)
+{
+  if (!pts || !primes || !bias || !mul || !grad_out || !table_grad || !workspace)
+    return F2N_E_INVALID_ARG;
+  if (F != 1 && F != 2 && F != 4 && F != 8) return F2N_E_UNSUPPORTED;
+  if (!f2n_hash_args_ok(n, L, F, T, level_stride)) return F2N_E_INVALID_ARG;
+  int e = 0;
+  const float m = frexpf(grad_scale, &e);
+  if (!(grad_scale > 0.f) || m != 0.5f) return F2N_E_INVALID_ARG;
+  if (reinterpret_cast<uintptr_t>(workspace) & 255u) return F2N_E_INVALID_ARG;
+  if (workspace_bytes <= 0) return F2N_E_INVALID_ARG;
+  BinPlan pl = bin_plan(n, L, F, T, workspace_bytes);
+  if (!pl.ok) return F2N_E_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const bool p2 = is_pow2(T);
+  const float inv = 1.f / grad_scale;
+  const int combine = f2n_get_option(F2N_OPT_BWD_COMBINE) == 0 ? 1 : 0;
+  // level windows [stride*l, stride*l + T*F) do not overlap: a slice owns its elements alone
+  const bool disjoint = L == 1 || level_stride >= (int64_t)T * F;
+  const int64_t total_tiles = (n + kBinBlock - 1) / kBinBlock;
+
+  for (int64_t tile0 = 0; tile0 < total_tiles; tile0 += pl.chunk_tiles) {
+    const int64_t tiles = std::min(pl.chunk_tiles, total_tiles - tile0);
+    const int64_t p0 = tile0 * kBinBlock;
+    const int64_t n_c = std::min<int64_t>(n - p0, tiles * kBinBlock);
+    if (tiles != pl.chunk_tiles || tile0 == 0) layout_for(pl, L, F, tiles);
+    if (tiles * pl.groups > 0x7fffffff) return F2N_E_INVALID_ARG;
+    char * w = (char *)workspace;
+    uint32_t * a_counts = reinterpret_cast<uint32_t *>(w);
+    uint32_t * a_records = reinterpret_cast<uint32_t *>(w + pl.a_counts_bytes);
+    uint32_t * b_counts = reinterpret_cast<uint32_t *>(w + pl.a_counts_bytes + pl.a_records_bytes);
+    uint32_t * b_records =
+      reinterpret_cast<uint32_t *>(w + pl.a_counts_bytes + pl.a_records_bytes + pl.b_counts_bytes);
+
+    BinArgs ba;
+    ba.g_ld_point = g_ld_point;
+    ba.g_ld_chan = g_ld_chan;
+    ba.n = n_c;
+    ba.n_tiles = tiles;
+    ba.level_stride = level_stride;
+    ba.T = T;
+    ba.L = L;
+    ba.grad_scale = grad_scale;
+    ba.inv_scale = inv;
+    ba.n_buckets = pl.n_buckets;
+    ba.bshift = pl.bshift;
+    ba.groups = pl.groups;
+    ba.qcap = pl.qcap;
+    ba.qcap_comb = pl.qcap_comb;
+    ba.combine = combine;
+    ba.stats = g_bin_stats.load(std::memory_order_relaxed);
+    const int64_t tiles_g = tiles * pl.groups;
+    const dim3 grid_a((unsigned)tiles), block_a(kBinBlock);
+    F2N_DISPATCH_F(F, {
+      if (p2)
+        hipLaunchKernelGGL(
+          (hash_bwd_bin_kernel<FF, true>), grid_a, block_a, 0, s, pts + 3 * p0, primes, bias, mul,
+          grad_out + p0 * g_ld_point, table_grad, a_records, a_counts, ba);
+      else
+        hipLaunchKernelGGL(
+          (hash_bwd_bin_kernel<FF, false>), grid_a, block_a, 0, s, pts + 3 * p0, primes, bias, mul,
+          grad_out + p0 * g_ld_point, table_grad, a_records, a_counts, ba);
+      if (pl.log2_sub == 0) {
+        const dim3 grid_c((unsigned)pl.n_slices, (unsigned)L);
+        if (disjoint)
+          hipLaunchKernelGGL(
+            (hash_bwd_reduce_kernel<FF, true>), grid_c, dim3(kBinBlock), 0, s, a_records, a_counts,
+            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g);
+        else
+          hipLaunchKernelGGL(
+            (hash_bwd_reduce_kernel<FF, false>), grid_c, dim3(kBinBlock), 0, s, a_records, a_counts,
+            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g);
+      } else {
+        SplitArgs sa;
+        sa.a_records = a_records;
+        sa.a_counts = a_counts;
+        sa.b_records = b_records;
+        sa.b_counts = b_counts;
+        sa.table_grad = table_grad;
+        sa.level_stride = level_stride;
+        sa.n_tiles_g = tiles_g;
+        sa.inv_scale = inv;
+        sa.n_buckets = pl.n_buckets;
+        sa.bshift = pl.bshift;
+        sa.log2_sub = pl.log2_sub;
+        sa.qcap = pl.qcap;
+        sa.n_slices = pl.n_slices;
+        sa.tiles_per_part = pl.tiles_per_part;
+        sa.n_parts = pl.n_parts;
+        sa.cap2 = pl.cap2;
+        const dim3 grid_b((unsigned)pl.n_buckets, (unsigned)L, (unsigned)pl.n_parts);
+        hipLaunchKernelGGL((hash_bwd_split_kernel<FF>), grid_b, dim3(kSplitBlock), 0, s, sa);
+        const dim3 grid_c((unsigned)pl.n_slices, (unsigned)L);
+        if (disjoint)
+          hipLaunchKernelGGL(
+            (hash_bwd_reduce_runs_kernel<FF, true>), grid_c, dim3(kBinBlock), 0, s, b_records,
+            b_counts, table_grad, T, level_stride, inv, pl.n_slices, pl.n_parts, pl.cap2);
+        else
+          hipLaunchKernelGGL(
+            (hash_bwd_reduce_runs_kernel<FF, false>), grid_c, dim3(kBinBlock), 0, s, b_records,
+            b_counts, table_grad, T, level_stride, inv, pl.n_slices, pl.n_parts, pl.cap2);
+      }
+    })
+    if (hipGetLastError() != hipSuccess) return F2N_E_LAUNCH;
+  }
+  return F2N_OK;
+}

@@ -308,278 +308,6 @@ __global__ __launch_bounds__(kSliceBlock) void hash_bwd_sliced_kernel(
   }
 }
 
-// v3 ("binned"): one hash evaluation per (point, level), no global atomics on the hot path.
-//
-// Pass 1 (bin): a 256-thread workgroup takes a tile of 256 points of one level, forms the 8 corner
-//   contributions of each point (f16(f16(scale*g)*w) per channel -- exactly representable as f16, so a
-//   record is {row within slice, F halves}) and stores every record straight into the
-//   (level, tile, slice) region of a caller-provided workspace; the slot inside the region comes from
-//   an LDS counter (ds_add_rtn).  A tile's regions are contiguous (32 KiB at the reference size), the
-//   stores of one tile land within microseconds of each other and are merged in L2.  Per-region counts
-//   are written at the end, laid out [level][slice][tile] so pass 2 reads them coalesced.
-// Pass 2 (reduce): one workgroup per (level, slice) streams that slice's regions tile by tile,
-//   accumulates into 128 KiB of f32 LDS accumulators (ds_add_f32) and adds the slice into the table
-//   gradient with contiguous atomics.
-// A region holds kBinCap records against an average of 8*256/n_slices; overflow (skewed coarse
-// levels) is applied with direct global atomics, so results never depend on the capacity.  Versus v2
-// the hash arithmetic runs once instead of once per slice; the price is 2 x 8 bytes of streamed
-// traffic per contribution (F = 2) and a workspace of ~2x that volume.
-constexpr int kBinBlock = 1024;
-// LDS float atomics are slow on gfx950: ds_add_f32 / ds_pk_add_f16 sustain ~0.2 T lane-ops/s chip
-// wide, ds_add_u32 / ds_add_u64 ~2.4 T (tools/probes/lds_atomic_rate.hip: 170 vs 14 cycles per wave
-// instruction).  Every contribution is an f16 value, i.e. an integer multiple of 2^-24 below 2^16,
-// so the reduce pass accumulates them EXACTLY as 64-bit fixed point with ds_add_u64: 12x faster, and
-// the table gradient becomes independent of summation order (bitwise reproducible).
-constexpr int kBinAcc = 16384;  // 64-bit accumulators per slice (128 KiB)
-
-template <int F>
-struct BinRecord
-{
-  static constexpr int kWords = 1 + (F >= 2 ? F / 2 : 1);
-};
-
-template <int F>
-__device__ __forceinline__ float record_channel(const uint32_t * rec, int k)
-{
-  const uint32_t word = rec[1 + (F >= 2 ? k / 2 : 0)];
-  return h2f((uint16_t)((k & 1) ? (word >> 16) : (word & 0xffffu)));
-}
-
-// f16 bits -> value * 2^24 as a signed 64-bit integer (exact for every finite f16)
-__device__ __forceinline__ long long f16_bits_to_fixed(uint32_t hbits)
-{
-  const uint32_t e = (hbits >> 10) & 31u, m = hbits & 0x3ffu;
-  const unsigned long long mag =
-    e ? ((unsigned long long)(0x400u | m) << (e - 1u)) : (unsigned long long)m;
-  return (hbits & 0x8000u) ? -(long long)mag : (long long)mag;
-}
-
-template <int F>
-__device__ __forceinline__ uint32_t record_channel_bits(const uint32_t * rec, int k)
-{
-  const uint32_t word = rec[1 + (F >= 2 ? k / 2 : 0)];
-  return (k & 1) ? (word >> 16) : (word & 0xffffu);
-}
-
-constexpr int kBinQueueWords = 32768;  // 128 KiB of LDS record staging per tile
-
-template <int F, bool POW2>
-__global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
-  const float * __restrict__ pts, const int32_t * __restrict__ primes,
-  const float * __restrict__ bias, const float * __restrict__ mul,
-  const float * __restrict__ grad_out, int64_t g_ld_point, int64_t g_ld_chan,
-  float * __restrict__ table_grad, uint32_t * __restrict__ ws_records,
-  uint32_t * __restrict__ ws_counts, int64_t n, int L, uint32_t T, int64_t level_stride,
-  float grad_scale, float inv_scale, int n_slices, int qcap, int64_t n_tiles)
-{
-  constexpr int RW = BinRecord<F>::kWords;
-  constexpr uint32_t kRows = kBinAcc / F;
-  // records are staged per slice in LDS and leave as whole contiguous regions instead of 64
-  // scattered 8-byte stores per instruction
-  __shared__ uint32_t queue[kBinQueueWords];
-  __shared__ uint32_t qcount[64];
-  // One workgroup owns a tile of points for ALL levels: the point is read once, and the gradient
-  // channels of level l+1 are requested before level l is processed -- with a 128 KiB LDS stage only
-  // one workgroup fits a CU, so nothing else would hide that load.
-  const int64_t tile = blockIdx.x;
-  const int64_t p = tile * kBinBlock + threadIdx.x;
-  const bool valid = p < n;
-  const int64_t pc = valid ? p : n - 1;
-  const float x = pts[3 * pc + 0], y = pts[3 * pc + 1], z = pts[3 * pc + 2];
-  const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
-
-  float g_cur[F], g_nxt[F];
-#pragma unroll
-  for (int k = 0; k < F; k++) g_cur[k] = grad_out[pc * g_ld_point + (int64_t)k * g_ld_chan];
-
-  for (int l = 0; l < L; l++) {
-    if (threadIdx.x < 64) qcount[threadIdx.x] = 0u;
-    {
-      const int ln = (l + 1 < L) ? l + 1 : l;  // clamped: the last prefetch re-reads level L-1
-#pragma unroll
-      for (int k = 0; k < F; k++)
-        g_nxt[k] = grad_out[pc * g_ld_point + (int64_t)(ln * F + k) * g_ld_chan];
-    }
-    __syncthreads();
-
-    float gk[F];
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < F; k++) {
-      gk[k] = round_f16(g_cur[k] * grad_scale);
-      any |= (gk[k] != 0.f);
-    }
-    if (valid && any) {
-      const LevelParams lp = load_level(primes, bias, mul, l);
-      uint32_t row[8];
-      float w[8];
-      corner_rows_and_weights<POW2>(x, y, z, lp, T, row, w);
-      float * gbase = table_grad + level_stride * l;
-#pragma unroll
-      for (int d = 0; d < 8; d++) {
-        uint32_t rec[RW];
-        const uint32_t slice = row[d] / kRows;
-        rec[0] = row[d] - slice * kRows;
-        if constexpr (F == 1) {
-          float c0 = gk[0] * w[d];
-          asm volatile("" : "+v"(c0));  // keep the f32 rounding before the f16 one (see round_f16)
-          rec[1] = (uint32_t)__half_as_ushort(__float2half_rn(c0));
-        } else {
-#pragma unroll
-          for (int k = 0; k < F; k += 2) {
-            float c0 = gk[k] * w[d], c1 = gk[k + 1] * w[d];
-            asm volatile("" : "+v"(c0), "+v"(c1));
-            rec[1 + k / 2] = (uint32_t)__half_as_ushort(__float2half_rn(c0)) |
-                             ((uint32_t)__half_as_ushort(__float2half_rn(c1)) << 16);
-          }
-        }
-        const uint32_t slot = atomicAdd(&qcount[slice], 1u);
-        if (slot < (uint32_t)qcap) {
-          uint32_t * q = queue + ((size_t)slice * qcap + slot) * RW;
-          if constexpr (RW == 2) {
-            *reinterpret_cast<uint2 *>(q) = make_uint2(rec[0], rec[1]);
-          } else {
-#pragma unroll
-            for (int j = 0; j < RW; j++) q[j] = rec[j];
-          }
-        } else {
-          // region full: apply this contribution directly
-#pragma unroll
-          for (int k = 0; k < F; k++) {
-            const float v = record_channel<F>(rec, k);
-            if (v != 0.f) atomicAdd(gbase + (int64_t)row[d] * F + k, v * inv_scale);
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // flush: wave w copies the queues of slices w, w+16, ... to their workspace regions; the LDS
-    // reads of up to four slices are issued before the first store so their latencies overlap
-    uint32_t * region0 = ws_records + ((size_t)l * n_tiles + tile) * n_slices * (size_t)qcap * RW;
-    if constexpr (RW == 2) {
-      constexpr int kWavesPerBlock = kBinBlock / 64;
-      for (int s0 = wave; s0 < n_slices; s0 += 4 * kWavesPerBlock) {
-        uint2 v[4][4];
-        uint32_t cnt[4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-          const int sidx = s0 + a * kWavesPerBlock;
-          cnt[a] = sidx < n_slices ? min(qcount[sidx], (uint32_t)qcap) : 0u;
-          const uint2 * q = reinterpret_cast<const uint2 *>(queue + (size_t)sidx * qcap * RW);
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            if ((uint32_t)(lane + 64 * k) < cnt[a]) v[a][k] = q[lane + 64 * k];
-        }
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-          const int sidx = s0 + a * kWavesPerBlock;
-          uint2 * dst = reinterpret_cast<uint2 *>(region0 + (size_t)sidx * qcap * RW);
-#pragma unroll
-          for (int k = 0; k < 4; k++)
-            if ((uint32_t)(lane + 64 * k) < cnt[a]) dst[lane + 64 * k] = v[a][k];
-          for (uint32_t i = lane + 256; i < cnt[a]; i += 64)  // qcap > 256 (small slice counts)
-            dst[i] = reinterpret_cast<const uint2 *>(queue + (size_t)sidx * qcap * RW)[i];
-        }
-      }
-    } else {
-      for (int sidx = wave; sidx < n_slices; sidx += kBinBlock / 64) {
-        const uint32_t cnt = min(qcount[sidx], (uint32_t)qcap);
-        const uint32_t * q = queue + (size_t)sidx * qcap * RW;
-        uint32_t * dst = region0 + (size_t)sidx * qcap * RW;
-        for (uint32_t i = lane; i < cnt * RW; i += 64) dst[i] = q[i];
-      }
-    }
-    if ((int)threadIdx.x < n_slices)
-      ws_counts[((size_t)l * n_slices + threadIdx.x) * n_tiles + tile] =
-        min(qcount[threadIdx.x], (uint32_t)qcap);
-    __syncthreads();  // queues and counters are reused by the next level
-#pragma unroll
-    for (int k = 0; k < F; k++) g_cur[k] = g_nxt[k];
-  }
-}
-
-constexpr int kRegionsInFlight = 8;  // regions a wave loads before it accumulates them
-
-template <int F>
-__global__ __launch_bounds__(kSliceBlock) void hash_bwd_reduce_kernel(
-  const uint32_t * __restrict__ ws_records, const uint32_t * __restrict__ ws_counts,
-  float * __restrict__ table_grad, uint32_t T, int64_t level_stride, float inv_scale, int n_slices,
-  int qcap, int64_t n_tiles)
-{
-  constexpr int RW = BinRecord<F>::kWords;
-  constexpr uint32_t kRows = kBinAcc / F;
-  constexpr int kWaves = kSliceBlock / 64;
-  __shared__ unsigned long long acc[kBinAcc];
-  const int sidx = blockIdx.x, l = blockIdx.y;
-  const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < kBinAcc; i += kSliceBlock) acc[i] = 0ull;
-  __syncthreads();
-
-  const uint32_t * counts = ws_counts + ((size_t)l * n_slices + sidx) * n_tiles;
-  const size_t tile_stride = (size_t)n_slices * qcap * RW;  // words between tiles, same slice
-  const uint32_t * base = ws_records + ((size_t)l * n_tiles * n_slices + sidx) * (size_t)qcap * RW;
-  const int n_half = (qcap + 63) / 64;  // 64-lane loads per region (1 or 2)
-  // a wave owns 64 consecutive tiles at a time: one coalesced load fetches their counts, then the
-  // regions are read four tiles at a time so several loads are in flight per lane
-  for (int64_t t0 = (int64_t)wave * 64; t0 < n_tiles; t0 += (int64_t)kWaves * 64) {
-    const uint32_t my_cnt = (t0 + lane < n_tiles) ? counts[t0 + lane] : 0u;
-    const int n_here = (int)min((int64_t)64, n_tiles - t0);
-    for (int j0 = 0; j0 < n_here; j0 += kRegionsInFlight) {
-      uint32_t cnt[kRegionsInFlight];
-      uint32_t cnt_max = 0u;
-#pragma unroll
-      for (int u = 0; u < kRegionsInFlight; u++) {
-        cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (j0 + u) & 63);
-        if ((j0 + u) >= n_here) cnt[u] = 0u;
-        cnt_max = max(cnt_max, cnt[u]);
-      }
-      for (int h = 0; h < n_half && (uint32_t)(64 * h) < cnt_max; h++) {  // wave-uniform bound
-        uint32_t rec[kRegionsInFlight][RW];
-#pragma unroll
-        for (int u = 0; u < kRegionsInFlight; u++) {
-          const bool live = (j0 + u) < n_here;
-          const uint32_t * region = base + (size_t)(t0 + (live ? j0 + u : 0)) * tile_stride;
-          // branch-free load so the four loads are in flight together: lanes past the region's
-          // count re-read its last record (same cache lines, no extra traffic) and skip it below
-          const uint32_t last = cnt[u] ? cnt[u] - 1u : 0u;
-          const uint32_t i = min((uint32_t)(lane + 64 * h), last);
-          if constexpr (RW == 2) {
-            const uint2 r = *reinterpret_cast<const uint2 *>(region + (size_t)i * 2);
-            rec[u][0] = r.x;
-            rec[u][1] = r.y;
-          } else {
-#pragma unroll
-            for (int w = 0; w < RW; w++) rec[u][w] = region[(size_t)i * RW + w];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kRegionsInFlight; u++) {
-          if ((uint32_t)(lane + 64 * h) < cnt[u]) {
-#pragma unroll
-            for (int k = 0; k < F; k++) {
-              const uint32_t hb = record_channel_bits<F>(rec[u], k);
-              if (hb & 0x7fffu)
-                atomicAdd(&acc[rec[u][0] * F + k], (unsigned long long)f16_bits_to_fixed(hb));
-            }
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  const uint32_t row_lo = (uint32_t)sidx * kRows;
-  float * gbase = table_grad + level_stride * l + (int64_t)row_lo * F;
-  const uint32_t rows_here = (row_lo + kRows <= T) ? kRows : (T > row_lo ? T - row_lo : 0u);
-  const int n_flush = (int)rows_here * F;
-  const double unit = (double)inv_scale * (1.0 / 16777216.0);
-  for (int i = threadIdx.x; i < n_flush; i += kSliceBlock) {
-    const long long v = (long long)acc[i];
-    if (v != 0) atomicAdd(gbase + i, (float)((double)v * unit));
-  }
-}
-
 // ---------------------------------------------------------------------------- contraction ------
 
 __global__ __launch_bounds__(F2N_BLOCK) void contract_fwd_kernel(
@@ -627,12 +355,6 @@ __global__ __launch_bounds__(F2N_BLOCK) void contract_bwd_kernel(
 
 inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1u)); }
 
-inline bool hash_args_ok(int64_t n, int L, int F, uint32_t T, int64_t level_stride)
-{
-  return n >= 0 && L >= 1 && L <= F2N_MAX_LEVELS && T >= 1 && level_stride >= 0 &&
-         (F == 1 || F == 2 || F == 4 || F == 8) && (level_stride % F) == 0;
-}
-
 }  // namespace
 
 extern "C" int f2n_table_to_f16(
@@ -666,7 +388,7 @@ extern "C" int f2n_hash_fwd(
 {
   if (!pts || !table_f16 || !primes || !bias || !mul || !out) return F2N_E_INVALID_ARG;
   if (F != 1 && F != 2 && F != 4 && F != 8) return F2N_E_UNSUPPORTED;
-  if (!hash_args_ok(n, L, F, T, level_stride)) return F2N_E_INVALID_ARG;
+  if (!f2n_hash_args_ok(n, L, F, T, level_stride)) return F2N_E_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(table_f16) % (2u * F)) return F2N_E_INVALID_ARG;
   if (n == 0) return F2N_OK;
   const dim3 grid(f2n_div_up(n, F2N_BLOCK), (unsigned)L), block(F2N_BLOCK);
@@ -695,7 +417,7 @@ extern "C" int f2n_hash_fwd_raytile(
   if (n_rays < 0 || S <= 0) return F2N_E_INVALID_ARG;
   if (S % 16) return F2N_E_UNSUPPORTED;  // callers fall back to f2n_hash_fwd
   const int64_t n = (int64_t)n_rays * S;
-  if (!hash_args_ok(n, L, F, T, level_stride)) return F2N_E_INVALID_ARG;
+  if (!f2n_hash_args_ok(n, L, F, T, level_stride)) return F2N_E_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(table_f16) % (2u * F)) return F2N_E_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(out_cm) & 15u) return F2N_E_INVALID_ARG;
   if (n == 0) return F2N_OK;
@@ -732,7 +454,7 @@ extern "C" int f2n_hash_bwd(
   if (!pts || !table_f16 || !primes || !bias || !mul || !grad_out || !table_grad)
     return F2N_E_INVALID_ARG;
   if (F != 1 && F != 2 && F != 4 && F != 8) return F2N_E_UNSUPPORTED;
-  if (!hash_args_ok(n, L, F, T, level_stride)) return F2N_E_INVALID_ARG;
+  if (!f2n_hash_args_ok(n, L, F, T, level_stride)) return F2N_E_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(table_f16) % (2u * F)) return F2N_E_INVALID_ARG;
   int e = 0;
   const float m = frexpf(grad_scale, &e);
@@ -784,92 +506,6 @@ extern "C" int f2n_hash_bwd(
     }
   })
 #undef F2N_BWD_LAUNCH
-  return f2n_launch_status();
-}
-
-namespace
-{
-
-struct BinPlan
-{
-  int n_slices = 0;
-  int qcap = 0;
-  int64_t n_tiles = 0;
-  int64_t counts_bytes = 0;
-  int64_t bytes = 0;
-};
-
-// Capacities of the binned backward for (n, L, F, T); n_slices == 0 means "not applicable".
-BinPlan bin_plan(int64_t n, int L, int F, uint32_t T, int64_t workspace_bytes)
-{
-  BinPlan pl;
-  if (!(F == 1 || F == 2 || F == 4 || F == 8) || L < 1 || n < 65536) return pl;
-  const int rw = 1 + (F >= 2 ? F / 2 : 1);
-  const int64_t rows_per_slice = kBinAcc / F;
-  const int64_t n_slices = ((int64_t)T + rows_per_slice - 1) / rows_per_slice;
-  if (n_slices > 64) return pl;
-  const int64_t n_tiles = (n + kBinBlock - 1) / kBinBlock;
-  const int avg = (8 * kBinBlock + (int)n_slices - 1) / (int)n_slices;  // records per region
-  // two 64-lane loads per region in the reduce kernel, and the tile's queues must fit the LDS stage
-  int qcap = std::min(2 * avg, kBinQueueWords / ((int)n_slices * rw));
-  if (qcap < avg + avg / 4) return pl;
-  pl.counts_bytes = ((int64_t)L * n_slices * n_tiles * 4 + 255) / 256 * 256;
-  if (workspace_bytes > 0) {
-    const int64_t fit =
-      (workspace_bytes - pl.counts_bytes) / ((int64_t)L * n_tiles * n_slices * rw * 4);
-    if (fit < avg / 2) return pl;  // too small to be worth it
-    qcap = (int)std::min<int64_t>(qcap, fit);
-  }
-  pl.n_slices = (int)n_slices;
-  pl.qcap = qcap;
-  pl.n_tiles = n_tiles;
-  pl.bytes = pl.counts_bytes + (int64_t)L * n_tiles * n_slices * qcap * rw * 4;
-  return pl;
-}
-
-}  // namespace
-
-extern "C" int64_t f2n_hash_bwd_workspace_bytes(int64_t n, int L, int F, uint32_t T)
-{
-  return bin_plan(n, L, F, T, 0).bytes;
-}
-
-extern "C" int f2n_hash_bwd_binned(
-  const float * pts, const int32_t * primes, const float * bias, const float * mul,
-  const float * grad_out, int64_t g_ld_point, int64_t g_ld_chan, float * table_grad, int64_t n,
-  int L, int F, uint32_t T, int64_t level_stride, float grad_scale, void * workspace,
-  int64_t workspace_bytes, void * stream)
-{
-  if (!pts || !primes || !bias || !mul || !grad_out || !table_grad || !workspace)
-    return F2N_E_INVALID_ARG;
-  if (F != 1 && F != 2 && F != 4 && F != 8) return F2N_E_UNSUPPORTED;
-  if (!hash_args_ok(n, L, F, T, level_stride)) return F2N_E_INVALID_ARG;
-  int e = 0;
-  const float m = frexpf(grad_scale, &e);
-  if (!(grad_scale > 0.f) || m != 0.5f) return F2N_E_INVALID_ARG;
-  if (reinterpret_cast<uintptr_t>(workspace) & 255u) return F2N_E_INVALID_ARG;
-  const BinPlan pl = bin_plan(n, L, F, T, workspace_bytes);
-  if (pl.n_slices == 0 || pl.bytes > workspace_bytes) return F2N_E_UNSUPPORTED;
-  hipStream_t s = (hipStream_t)stream;
-  uint32_t * counts = reinterpret_cast<uint32_t *>(workspace);
-  uint32_t * records = reinterpret_cast<uint32_t *>((char *)workspace + pl.counts_bytes);
-  const bool p2 = is_pow2(T);
-  const float inv = 1.f / grad_scale;
-  const dim3 grid1((unsigned)pl.n_tiles), block1(kBinBlock);
-  const dim3 grid2((unsigned)pl.n_slices, (unsigned)L), block2(kSliceBlock);
-#define F2N_BIN(P2)                                                                               \
-  hipLaunchKernelGGL(                                                                             \
-    (hash_bwd_bin_kernel<FF, P2>), grid1, block1, 0, s, pts, primes, bias, mul, grad_out,         \
-    g_ld_point, g_ld_chan, table_grad, records, counts, n, L, T, level_stride, grad_scale, inv,   \
-    pl.n_slices, pl.qcap, pl.n_tiles)
-  F2N_DISPATCH_F(F, {
-    if (p2) F2N_BIN(true);
-    else F2N_BIN(false);
-    hipLaunchKernelGGL(
-      (hash_bwd_reduce_kernel<FF>), grid2, block2, 0, s, records, counts, table_grad, T,
-      level_stride, inv, pl.n_slices, pl.qcap, pl.n_tiles);
-  })
-#undef F2N_BIN
   return f2n_launch_status();
 }
 

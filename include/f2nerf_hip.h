@@ -100,12 +100,17 @@ int f2n_hash_bwd(
   float grad_scale, void * stream);
 
 /* Same operation as f2n_hash_bwd without the point gradient, for large batches: contributions are
- * binned by table slice into a caller-provided workspace and reduced in LDS, so the scattered
- * f16/f32 atomics of Hash3DAnchoredBackwardKernel (src/hash_3d_anchored.cu:129-137) disappear.
- * f2n_hash_bwd_workspace_bytes returns the recommended workspace size, or 0 when the binned path
- * does not apply to (n, L, F, T) -- use f2n_hash_bwd then.  workspace: device memory, 256-byte
- * aligned, contents undefined on entry and exit; a smaller workspace only lowers the capacity
- * (overflow is applied with direct atomics, results are unaffected). */
+ * binned by table slice into a caller-provided workspace and summed EXACTLY (64-bit fixed point) in
+ * LDS, so the scattered f16/f32 atomics of Hash3DAnchoredBackwardKernel
+ * (src/hash_3d_anchored.cu:129-137) disappear and the result does not depend on summation order.
+ * Tables with more than 64 LDS-sized slices per level (T*F > 2^20, e.g. T = 2^22, F = 8) take a
+ * second binning pass; coarse levels whose cells are shared by the points of a tile are combined
+ * before they are binned (F2N_OPT_BWD_COMBINE).
+ * f2n_hash_bwd_workspace_bytes returns the recommended workspace size (at most 24 GiB), or 0 when
+ * the binned path does not apply to (n, L, F, T): n < 65536 or T*F > 2^26 -- use f2n_hash_bwd then.
+ * workspace: device memory, 256-byte aligned, contents undefined on entry and exit.  A smaller
+ * workspace makes the passes run in several rounds over the points (same results);
+ * F2N_E_UNSUPPORTED when it cannot hold one 1024-point tile. */
 int64_t f2n_hash_bwd_workspace_bytes(int64_t n, int L, int F, uint32_t T);
 int f2n_hash_bwd_binned(
   const float * pts, const int32_t * primes, const float * bias, const float * mul,

@@ -161,9 +161,15 @@ def test_hash_bwd_sliced_path(capi, dev, L, F, T, stride, n):
     (16, 2, 19, "ref", 70000, 0.3),     # small workspace: region overflow -> direct atomics
     (4, 4, 17, "disjoint", 66000, 1.0),
     (3, 1, 20, "disjoint", 66000, 1.0),
+    # more than 64 slices per level: two-level binning (bucket = 2^k slices, split pass, run reduce)
+    (3, 8, 18, "disjoint", 70000, 1.0),     # 128 slices = 64 buckets x 2, 2 point rounds per tile
+    (2, 8, 20, "disjoint", 70000, 1.0),     # 512 slices = 64 x 8
+    (2, 2, 21, "disjoint", 70000, 1.0),     # F = 2 records through the split pass: 256 slices
+    (2, 4, 19, "ref", 70000, 0.4),          # 128 slices, overlapping level windows, several rounds
 ])
 def test_hash_bwd_binned_path(capi, dev, L, F, log2_T, stride_mode, n, ws_frac):
-    """Binned backward (bin into workspace + LDS reduce): same contributions as the atomic kernel."""
+    """Binned backward (bin into workspace + LDS reduce): same contributions as the atomic kernel.
+    A workspace smaller than recommended makes the passes run in several rounds over the points."""
     T = 1 << log2_T
     fld = util.make_field(L, F, log2_T, None if stride_mode == "ref" else T * F, seed=5 + F)
     st = fld["stride"]
@@ -191,6 +197,90 @@ def test_hash_bwd_binned_path(capi, dev, L, F, log2_T, stride_mode, n, ws_frac):
               T, st, 128.0, ws, nbytes)
     assert (tg2.cpu() - ref_tg).abs().max().item() <= 2e-5 * scale
     assert capi.lib().cdll.f2n_hash_bwd_workspace_bytes(100, L, F, T) == 0   # small n: not applicable
+
+
+def _ray_points(n_rays, S, seed):
+    """Contracted samples of random rays, ray-major (what the renderer feeds the backward): consecutive
+    points share coarse cells, which is what the per-tile combine of the binned backward feeds on."""
+    g = torch.Generator().manual_seed(seed)
+    o = torch.randn(n_rays, 1, 3, generator=g) * 0.3
+    d = torch.randn(n_rays, 1, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    t = (torch.arange(1, S + 1).float() * (4.0 / S)).reshape(1, S, 1)
+    p = (o + d * t).reshape(-1, 3)
+    nrm = p.norm(dim=1, keepdim=True)
+    return torch.where(nrm <= 1, p, (2 - 1 / nrm) * p / nrm).contiguous()
+
+
+@pytest.mark.parametrize("L,F,log2_T,S", [(16, 2, 19, 128), (8, 4, 16, 1024), (6, 1, 19, 256)])
+def test_hash_bwd_binned_combine(capi, dev, L, F, log2_T, S):
+    """Ray-coherent points: coarse levels are combined per tile (sums leave as f16 pieces), fine
+    levels are not; with the combine switched off the very same table gradient must come out bit
+    for bit wherever no capacity overflowed (both are exact sums), and both match the oracle."""
+    T = 1 << log2_T
+    fld = util.make_field(L, F, log2_T, None, seed=3 + F)
+    n_rays = 66560 // S + 1
+    pts = _ray_points(n_rays, S, seed=31)
+    n = pts.shape[0]
+    g = torch.Generator().manual_seed(32)
+    grad = torch.randn(n, L * F, generator=g) * 1e-3 * torch.rand(n, 1, generator=g) ** 4
+    grad[torch.rand(n, L * F, generator=g) < 0.05] = 0.0
+    numel = fld["table"].numel()
+    ref_tg, _ = K.hash_bwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad,
+                           numel, L, F, T, fld["stride"], 128.0, parallel=True)
+    need = capi.lib().cdll.f2n_hash_bwd_workspace_bytes(n, L, F, T)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    d = _to(dev, pts, fld["primes"], fld["bias"], fld["mul"], grad.t().contiguous())
+    out = {}
+    for combine_off in (0, 1):
+        with capi.option("BWD_COMBINE", combine_off):
+            tg = torch.zeros(numel, device=dev)
+            capi.call("hash_bwd_binned", *d, 1, n, tg, n, L, F, T, fld["stride"], 128.0, ws, need)
+            out[combine_off] = tg.cpu()
+    scale = ref_tg.abs().max().item()
+    for k, tg in out.items():
+        assert (tg - ref_tg).abs().max().item() <= 2e-5 * scale, k
+        assert ((tg - ref_tg).norm() / ref_tg.norm()).item() < 1e-5, k
+    # exact sums either way: only entries touched by an overflow fallback (float atomics) may differ
+    assert (out[0] != out[1]).float().mean().item() < 0.02
+    assert (out[0] - out[1]).abs().max().item() <= 1e-6 * scale
+
+
+@pytest.mark.parametrize("route", ["binned", "binned_nocombine", "sliced", "atomic"])
+def test_hash_bwd_nonfinite_gradient_propagates(capi, dev, route):
+    """An incoming gradient beyond the f16 range (128*g overflows to inf) must poison the rows it
+    touches on every route, as the reference's f16 atomics would -- not vanish into a finite sum
+    (f16_bits_to_fixed had no case for exponent 31)."""
+    L, F, log2_T = 4, 2, 19
+    T = 1 << log2_T
+    fld = util.make_field(L, F, log2_T, None, seed=9)
+    pts = _ray_points(520, 128, seed=5)
+    n = pts.shape[0]
+    g = torch.Generator().manual_seed(6)
+    grad = torch.randn(n, L * F, generator=g) * 1e-3
+    bad_p, bad_c = 777, 3                      # level 1, channel 1
+    grad[bad_p, bad_c] = 1.0e3                 # 128e3 > 65504 -> +inf as f16
+    numel = fld["table"].numel()
+    ref_tg, _ = K.hash_bwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad,
+                           numel, L, F, T, fld["stride"], 128.0)
+    assert not torch.isfinite(ref_tg).all()
+    d = _to(dev, pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad)
+    tg = torch.zeros(numel, device=dev)
+    if route.startswith("binned"):
+        need = capi.lib().cdll.f2n_hash_bwd_workspace_bytes(n, L, F, T)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        with capi.option("BWD_COMBINE", 1 if route.endswith("nocombine") else 0):
+            capi.call("hash_bwd_binned", d[0], d[2], d[3], d[4], d[5], L * F, 1, tg, n, L, F, T,
+                      fld["stride"], 128.0, ws, need)
+    else:
+        with capi.option("HASH_BWD", {"atomic": 1, "sliced": 2}[route]):
+            capi.call("hash_bwd", *d, L * F, 1, tg, None, n, L, F, T, fld["stride"], 128.0)
+    got = tg.cpu()
+    assert torch.equal(torch.isfinite(got), torch.isfinite(ref_tg))
+    fin = torch.isfinite(ref_tg)
+    scale = ref_tg[fin].abs().max().item()
+    assert (got[fin] - ref_tg[fin]).abs().max().item() <= 2e-5 * scale
 
 
 def test_table_cast(capi, dev):

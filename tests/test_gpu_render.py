@@ -78,6 +78,8 @@ def _close(a, b, rtol, atol_frac=1e-5):
     (16, 2, 19, 128, 4.0 / 128, 0.0),   # dense
     (4, 2, 19, 64, 4.0 / 64, 4.0),      # config C1 shape
     (16, 2, 19, 1024, 1.0 / 256, 7.0),  # reference-exact sampler (config C4), terminating
+    (16, 2, 19, 192, 4.0 / 192, 5.0),   # config C3: 192 samples per ray, step 4/192, terminating
+    (16, 2, 19, 192, 4.0 / 192, 0.0),   # config C3, dense
 ])
 def test_train_step_matches_oracle(host, dev, L, F, log2_T, S, step, bias0):
     n_rays = 48
@@ -126,6 +128,42 @@ def test_train_step_matches_oracle(host, dev, L, F, log2_T, S, step, bias0):
                 _close(got.cpu(), ref, 1e-3, 1e-3)
                 assert ((got.cpu() - ref).norm() / ref.norm()) < 5e-4
         assert grads["scene_field.bias_pool"] is None or float(grads["scene_field.bias_pool"].abs().sum()) == 0
+
+
+def test_config_c3_view_chunk_properties(host, dev):
+    """BASELINE config C3 at its own size: one 1920 x 1080 free-trajectory view, 192 samples per ray.
+    The oracle needs minutes at this size, so the full-width chunk is checked through properties:
+    (a) the first 32 rays of the chunk against the oracle (same pixels, same parameters);
+    (b) chunking invariance: rendering rows 540..541 (3840 rays) in one piece or in chunks of 1000
+        gives the same pixels; (c) colours are convex combinations of sigmoid outputs and the
+        background, depths lie inside the sampled range."""
+    L, F, log2_T, S, step = 16, 2, 19, 192, 4.0 / 192
+    oracle, hr, *_ = _setup(host, L, F, log2_T, S, step, 4, 3.0, 61)
+    H, W = 1080, 1920
+    pose = torch.tensor([[0.8, 0.0, 0.6, 0.45], [0.0, 1.0, 0.0, -0.1], [-0.6, 0.0, 0.8, 0.55]])
+    K = torch.tensor([[1400.0, 0, W / 2], [0, 1400.0, H / 2], [0, 0, 1]])
+    o, d = host.get_view_rays(pose.to(dev), K.to(dev), H, W)
+    assert tuple(o.shape) == (H * W, 3)
+    lo = 540 * W
+    o2, d2 = o[lo:lo + 2 * W].contiguous(), d[lo:lo + 2 * W].contiguous()
+    with torch.no_grad():
+        c_one, z_one = hr.render_all_rays(o2, d2, 2 * W)
+        c_chk, z_chk = hr.render_all_rays(o2, d2, 1000)
+        ii = torch.full((32,), 540.0)
+        jj = torch.arange(32, dtype=torch.float32)
+        ro, rd = R.get_rays_from_pose(pose[None], K[None], torch.stack([ii, jj], -1))
+        ref = oracle.render(ro, rd, None, R.VALIDATE)
+    _close(c_one[:32].cpu(), ref.colors, 1e-4)
+    _close(z_one[:32].cpu().squeeze(-1), ref.depths, 1e-4)
+    torch.testing.assert_close(c_one, c_chk, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(z_one, z_chk, rtol=1e-6, atol=1e-6)
+    assert float(c_one.min()) >= -1e-3 - 1e-6 and float(c_one.max()) <= 1 + 1e-3 + 1e-6
+    assert float(z_one.min()) >= 0 and float(z_one.max()) <= 4.0 + 0.01 + 1e-3
+    # the whole view renders (11 chunks of 192 x 1080 = 207 360 rays ... here: 65 536-ray chunks)
+    with torch.no_grad():
+        img, dep = hr.render_image(pose.to(dev), K.to(dev), H, W, 65536)
+    assert tuple(img.shape) == (H, W, 3) and bool(torch.isfinite(img).all())
+    torch.testing.assert_close(img[540:542].reshape(-1, 3), c_one.clip(0, 1), rtol=1e-6, atol=1e-6)
 
 
 def test_validate_render_and_image(host, dev):
