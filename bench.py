@@ -55,6 +55,15 @@ def parse_args():
                     help="torch.distributed backend; nccl = RCCL (default). 'gloo' + --share-gpu lets "
                          "several ranks rehearse the multi-rank path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
+    ap.add_argument("--workload", choices=["render", "c5"], default="render",
+                    help="render: the headline (BASELINE config C2 shape by default; C1/C3/C4 through "
+                         "--levels/--samples/--height/--width/--rays).  c5: BASELINE config C5, the "
+                         "hash-grid kernels alone (forward + backward) on 2^24 uniform points of the "
+                         "radius-2 ball, T = 2^22, L = 16, F = 8, 1 GiB f16 table -- the HBM stress; "
+                         "reports points/s with a roofline object per kernel")
+    ap.add_argument("--c5-points", type=int, default=1 << 24)
+    ap.add_argument("--c5-workspace-gib", type=float, default=0.0,
+                    help="scratch for the binned backward (0 = the library's recommendation)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="kernel route for A/B measurements (f2n_set_option), e.g. BWD_COMBINE=1; "
                          "recorded in the JSON line")
@@ -296,6 +305,135 @@ def dry_run(args, rank, world):
     return 0
 
 
+def run_c5(args, rank, world, dist, dev, pkg):
+    """BASELINE config C5: hash-grid encode forward + table-gradient backward through the C ABI,
+    inputs resident in HBM; one step = both kernels over the whole point set."""
+    capi = pkg.capi
+    L, F, log2_T = 16, 8, 22
+    T, C, n = 1 << log2_T, 16 * 8, args.c5_points
+    stride = T * F                                   # non-overlapping level windows (BASELINE.md C5)
+    numel = T * L * F
+    g = torch.Generator(device=dev).manual_seed(2022 + rank)
+    table = torch.randn(numel, device=dev, generator=g) * 0.1
+    table16 = torch.empty(numel, dtype=torch.int16, device=dev)
+    capi.call("table_to_f16", table, table16, numel)
+    del table
+    primes = (torch.randint(1 << 28, 1 << 30, (L, 3), device=dev, generator=g) | 1).to(torch.int32)
+    bias = torch.rand(L, 3, device=dev, generator=g) * 1000 + 100
+    mul = torch.tensor([2.0 ** (7.0 * l / (L - 1) + 3.0) for l in range(L)], device=dev)
+    dd = torch.randn(n, 3, device=dev, generator=g)
+    pts = (dd / dd.norm(dim=1, keepdim=True) * torch.rand(n, 1, device=dev, generator=g) ** (1 / 3) * 2).contiguous()
+    del dd
+    enc = torch.empty(C, n, device=dev)                                  # channel-major, as the host lib stores it
+    grad = torch.randn(C, n, device=dev, generator=g) * 1e-3
+    tg = torch.zeros(numel, device=dev)
+    need = capi.lib().cdll.f2n_hash_bwd_workspace_bytes(n, L, F, T)
+    if need <= 0:
+        raise SystemExit("binned backward does not cover config C5")
+    if args.c5_workspace_gib > 0:
+        need = int(args.c5_workspace_gib * 2 ** 30) // 256 * 256
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+
+    def fwd():
+        capi.call("hash_fwd", pts, table16, primes, bias, mul, enc, 1, n, None, n, L, F, T, stride)
+
+    def bwd():
+        capi.call("hash_bwd_binned", pts, primes, bias, mul, grad, 1, n, tg, n, L, F, T, stride, 128.0, ws, need)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        fwd()
+        bwd()
+    barrier()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s_ in range(args.steps):
+        evs[s_][0].record()
+        fwd()
+        evs[s_][1].record()
+        bwd()
+        evs[s_][2].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t_max = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    if rank != 0:
+        return
+    ms_f = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
+    ms_b = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
+    b_f, b_b = algorithmic_bytes("hash_fwd", L, F, 0), algorithmic_bytes("hash_bwd", L, F, 0)
+
+    def roof(op, ms, bytes_unit):
+        a = n * bytes_unit / (ms * 1e-3) / 1e9
+        traffic, src = pmc_traffic(op, "c5")
+        return {"kernel": op, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": a / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                "algorithmic_bytes_per_launch": n * bytes_unit, "avg_launch_ms": ms}
+
+    out = {
+        "metric": "hash-grid points/sec (encode fwd + table-gradient bwd), BASELINE config C5",
+        "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "C5: %d uniform points in the radius-2 ball, T=2^22 L=16 F=8, 1 GiB f16 table, "
+                               "non-overlapping level stride; f2n_hash_fwd + f2n_hash_bwd_binned" % n,
+                   "workspace_GiB": need / 2 ** 30, "sharding": "independent point sets per rank"},
+        "kernel_options": args.option,
+        "roofline": roof("hash_bwd", ms_b, b_b),
+        "roofline_fwd": roof("hash_fwd", ms_f, b_f),
+        "note": "the forward gathers one random 128-byte line per 16-byte row: it runs at the measured "
+                "random-line rate of the memory system (profiles/r02_gather_policy_probe.txt), which caps "
+                "the algorithmic fraction at 16/128 of the line traffic",
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline_c5(L, F, log2_T)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "points/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "failed: %r" % (e,)}
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_c5(L, F, log2_T, n=1 << 20):
+    """The oracle's hash encode forward + backward (C/OpenMP restatement of the reference's two CUDA
+    kernels) on a bounded sample of config C5: same table size, 2^20 points."""
+    from oracle import kernels as K
+
+    cores = int(os.environ.get("F2N_CPU_THREADS", "0")) or min(usable_cores(), 64)
+    torch.set_num_threads(cores)
+    K.set_num_threads(cores)
+    T = 1 << log2_T
+    g = torch.Generator().manual_seed(5)
+    numel = T * L * F
+    table16 = K.cast_f16(torch.randn(numel, generator=g) * 0.1)
+    primes = (torch.randint(1 << 28, 1 << 30, (L, 3), generator=g) | 1).to(torch.int32)
+    bias = torch.rand(L, 3, generator=g) * 1000 + 100
+    mul = K.level_mul(L)
+    dd = torch.randn(n, 3, generator=g)
+    pts = (dd / dd.norm(dim=1, keepdim=True) * torch.rand(n, 1, generator=g) ** (1 / 3) * 2).contiguous()
+    grad = torch.randn(n, L * F, generator=g) * 1e-3
+    times = []
+    for it in range(2 + 5):
+        t0 = time.perf_counter()
+        K.hash_fwd(pts, table16, primes, bias, mul, L, F, T, T * F)
+        K.hash_bwd(pts, table16, primes, bias, mul, grad, numel, L, F, T, T * F, 128.0, parallel=True)
+        if it >= 2:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": n / med, "unit": "points/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "runs_s": [round(t, 4) for t in times],
+            "sample": "%d points of config C5 (same table), oracle hash fwd + bwd, median of 5 after 2 warm-ups" % n}
+
+
 def time_train_iterations(args, pkg, H, dev, dist, world, poses, intr):
     """K complete training iterations of the reference's batch (train_manager.cpp:66-107 minus
     logging): 512 rays per rank drawn on the device, S = 1024 / step 1/256, TRAIN render + loss +
@@ -394,6 +532,12 @@ def main():
     for kv in args.option:
         name, value = kv.split("=")
         pkg.capi.set_option(name, int(value))
+    if args.workload == "c5":
+        run_c5(args, rank, world, dist, dev, pkg)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     H.manual_seed(2022)          # reference main.cpp:11; identical parameters on every rank
     torch.manual_seed(2022)
     S, L, F = args.samples, args.levels, args.channels
