@@ -637,7 +637,6 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
 
 // ------------------------------------------------------------------------------ pass C: reduce -
 
-constexpr int kRegionsInFlight = 8;  // regions a wave loads before it accumulates them
 
 // Non-finite contributions (an incoming gradient beyond the f16 range) cannot enter the fixed-point
 // sums; they are remembered per accumulator as three bit sets {+inf, -inf, NaN} and folded in when
@@ -739,10 +738,12 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
   constexpr uint32_t kRows = kBinAcc / F;
   constexpr int kWaves = kBinBlock / 64;
   __shared__ SliceAcc acc;
+  __shared__ uint32_t batch_off[kWaves][64 + 1];
   const int sidx = blockIdx.x, l = blockIdx.y;
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
   zero_slice(acc);
+  if (threadIdx.x < kWaves) batch_off[threadIdx.x][64] = 0xffffffffu;  // sentinel for the search
   __syncthreads();
 
   const uint32_t row_lo = (uint32_t)sidx * kRows;
@@ -750,38 +751,64 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
   const uint32_t * counts = ws_counts + ((size_t)l * n_slices + sidx) * n_tiles;
   const size_t tile_stride = (size_t)n_slices * qcap * KW;  // words between tiles, same slice
   const uint32_t * base = ws_records + ((size_t)l * n_tiles * n_slices + sidx) * (size_t)qcap * KW;
-  const int n_half = (qcap + 63) / 64;  // 64-lane loads per region
-  // a wave owns 64 consecutive tiles at a time: one coalesced load fetches their counts, then the
-  // regions are read several tiles at a time so that many loads are in flight per lane
+  // A wave owns 64 consecutive tiles at a time.  One coalesced load fetches their counts; their
+  // records are then walked as ONE flat list (lane f handles the f-th record of the batch, found by
+  // a binary search over the scanned counts kept in LDS), so every load instruction has 64 busy
+  // lanes and a whole batch is in flight at once -- regions of a few records each (sparse
+  // gradients) cost no more than their records.
+  uint32_t * woff = &batch_off[wave][0];
+  constexpr int kFlat = 8;  // 64-record loads in flight per wave
   for (int64_t t0 = (int64_t)wave * 64; t0 < n_tiles; t0 += (int64_t)kWaves * 64) {
-    const uint32_t my_cnt = (t0 + lane < n_tiles) ? counts[t0 + lane] : 0u;
-    const int n_here = (int)min((int64_t)64, n_tiles - t0);
-    for (int j0 = 0; j0 < n_here; j0 += kRegionsInFlight) {
-      uint32_t cnt[kRegionsInFlight];
-      uint32_t cnt_max = 0u;
+    const uint32_t my_cnt = (t0 + lane < n_tiles) ? min(counts[t0 + lane], (uint32_t)qcap) : 0u;
+    const uint32_t incl = (uint32_t)wave_incl_scan_i32((int)my_cnt);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total > 64u * 40u) {
+      // well-filled regions (dense gradients): one 64-lane load per region and 64 records, several
+      // regions in flight; the search below would cost more than the idle tail lanes
+      constexpr int kRegions = 8;
+      const int n_here = (int)min((int64_t)64, n_tiles - t0);
+      const int n_half = (qcap + 63) / 64;
+      for (int j0 = 0; j0 < n_here; j0 += kRegions) {
+        uint32_t cnt[kRegions];
+        uint32_t cnt_max = 0u;
 #pragma unroll
-      for (int u = 0; u < kRegionsInFlight; u++) {
-        cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (j0 + u) & 63);
-        if ((j0 + u) >= n_here) cnt[u] = 0u;
-        cnt_max = max(cnt_max, cnt[u]);
-      }
-      for (int h = 0; h < n_half && (uint32_t)(64 * h) < cnt_max; h++) {  // wave-uniform bound
-        uint32_t r[kRegionsInFlight], v[kRegionsInFlight][VW];
-#pragma unroll
-        for (int u = 0; u < kRegionsInFlight; u++) {
-          const bool live = (j0 + u) < n_here;
-          const uint32_t * region = base + (size_t)(t0 + (live ? j0 + u : 0)) * tile_stride;
-          // branch-free load so the loads are in flight together: lanes past the region's count
-          // re-read its last record (same cache lines, no extra traffic) and skip it below
-          const uint32_t last = cnt[u] ? cnt[u] - 1u : 0u;
-          const uint32_t i = min((uint32_t)(lane + 64 * h), last);
-          load_record<F>(region, qcap, i, r[u], v[u]);
+        for (int u = 0; u < kRegions; u++) {
+          cnt[u] = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (j0 + u) & 63);
+          if ((j0 + u) >= n_here) cnt[u] = 0u;
+          cnt_max = max(cnt_max, cnt[u]);
         }
+        for (int h = 0; h < n_half && (uint32_t)(64 * h) < cnt_max; h++) {  // wave-uniform bound
+          uint32_t r[kRegions], v[kRegions][VW];
 #pragma unroll
-        for (int u = 0; u < kRegionsInFlight; u++)
-          if ((uint32_t)(lane + 64 * h) < cnt[u])
-            accumulate_record<F>(acc, r[u], v[u]);
+          for (int u = 0; u < kRegions; u++) {
+            const bool live = (j0 + u) < n_here;
+            const uint32_t * region = base + (size_t)(t0 + (live ? j0 + u : 0)) * tile_stride;
+            const uint32_t last = cnt[u] ? cnt[u] - 1u : 0u;  // tail lanes re-read the last record
+            load_record<F>(region, qcap, min((uint32_t)(lane + 64 * h), last), r[u], v[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < kRegions; u++)
+            if ((uint32_t)(lane + 64 * h) < cnt[u]) accumulate_record<F>(acc, r[u], v[u]);
+        }
       }
+      continue;
+    }
+    woff[lane] = incl - my_cnt;  // first flat index of tile `lane` (same-wave LDS accesses stay ordered)
+    for (uint32_t f0 = 0; f0 < total; f0 += 64 * kFlat) {
+      uint32_t r[kFlat], v[kFlat][VW];
+#pragma unroll
+      for (int u = 0; u < kFlat; u++) {
+        const uint32_t f = min(f0 + 64u * u + lane, total - 1u);  // branch-free: tail lanes re-read
+        uint32_t t = 0u;  // largest t with woff[t] <= f (empty tiles share an offset with their successor)
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1)
+          if (woff[t + step] <= f) t += step;
+        const uint32_t * region = base + (size_t)(t0 + t) * tile_stride;
+        load_record<F>(region, qcap, f - woff[t], r[u], v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kFlat; u++)
+        if (f0 + 64u * u + lane < total) accumulate_record<F>(acc, r[u], v[u]);
     }
   }
   __syncthreads();
