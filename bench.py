@@ -185,9 +185,13 @@ def pmc_traffic(op, workload_key="c2"):
                              "(now %s)" % kernels_sha16())
             return None, src
         tot = 0.0
+        launches = meta.get("operator_launches", 0)
         for k in OP_KERNELS.get(op, []):
             if k in d:
-                tot += d[k].get("read_bytes_corrected", 0.0) + d[k].get("write_bytes", 0.0)
+                per_dispatch = d[k].get("read_bytes_corrected", 0.0) + d[k].get("write_bytes", 0.0)
+                # an operator launch may be several dispatches of a kernel (rounds of the C5 backward)
+                mult = d[k].get("dispatches_per_pass", launches) / launches if launches else 1.0
+                tot += per_dispatch * mult
         return (tot or None), src
     except (KeyError, ValueError, OSError) as e:
         src["reason"] = "unreadable: %r" % (e,)

@@ -35,9 +35,13 @@ def main(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--command", default="")
+    ap.add_argument("--launches", type=int, default=0,
+                    help="operator launches in the profiled run (bench steps + warm-ups, times chunks per "
+                         "step): lets bench.py turn per-dispatch bytes into bytes per operator launch when "
+                         "an operator is several dispatches (the C5 backward runs in rounds)")
     ap.add_argument("dirs", nargs="+")
-    a = ap.parse_args(argv)
-    dirs = a.dirs
+    opts = ap.parse_args(argv)
+    dirs = opts.dirs
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for d in dirs:
         for f in glob.glob(d + "/*/*counter_collection.csv"):
@@ -53,7 +57,8 @@ def main(argv):
                 t[1] += 1
     out = {}
     for k, cs in sorted(acc.items()):
-        e = {"dispatches": max(v[1] for v in cs.values())}
+        e = {"dispatches": max(v[1] for v in cs.values()),
+             "dispatches_per_pass": max(v[1] for c, v in cs.items() if c != "duration_us")}
         for c, (tot, n) in cs.items():
             e[c + "_avg"] = tot / n
         if "FETCH_SIZE_avg" in e:
@@ -63,7 +68,7 @@ def main(argv):
             e["write_bytes"] = e["WRITE_SIZE_avg"] * 1024
         out[k] = e
     from bench import kernels_sha16
-    out["_meta"] = {"workload": a.workload, "kernels_sha16": kernels_sha16(), "command": a.command,
+    out["_meta"] = {"workload": opts.workload, "kernels_sha16": kernels_sha16(), "command": opts.command, "operator_launches": opts.launches,
                     "git_sha": os.environ.get("F2N_GIT_SHA", "")}
     json.dump(out, sys.stdout, indent=1)
     print()
