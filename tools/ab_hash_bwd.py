@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--points", default="train")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--ws-gib", type=float, default=0.0, help="workspace size (0 = recommended)")
+    ap.add_argument("--zero-rays", type=float, default=0.0, help="fraction of rays whose gradient is zero")
+    ap.add_argument("--grad-scale", type=float, default=1e-3, help="std of the synthetic gradient")
+    ap.add_argument("--levels", type=int, default=0, help="override L")
     args = ap.parse_args()
     capi = importlib.import_module("f2-nerf_amd").capi
     dev = torch.device("cuda:0")
@@ -71,6 +74,8 @@ def main():
            "c3": (16, 2, 19, False, 65536, 192),
            "c5": (16, 8, 22, True, 1 << 17, 128), "c5s": (16, 8, 22, True, 1 << 15, 128)}[args.config]
     L, F, log2_T, disjoint, n_rays, S = cfg
+    if args.levels:
+        L = args.levels
     T = 1 << log2_T
     stride = T * F if disjoint else T
     numel = max(T * L * F, stride * (L - 1) + T * F)
@@ -81,7 +86,10 @@ def main():
     pts = make_points(args.points, n_rays, S, dev, g)
     n = pts.shape[0]
     C = L * F
-    grad = torch.randn(C, n, device=dev, generator=g) * 1e-3
+    grad = torch.randn(C, n, device=dev, generator=g) * args.grad_scale
+    if args.zero_rays > 0:
+        dead = torch.rand(n_rays, device=dev, generator=g) < args.zero_rays
+        grad.view(C, n_rays, S)[:, dead, :] = 0.0
     tg = torch.zeros(numel, device=dev)
     bytes_alg = 12 + 20 * C
     libs = [("current", capi.lib().cdll)]
