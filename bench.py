@@ -164,6 +164,20 @@ def kernels_sha16():
     return h.hexdigest()[:16]
 
 
+def workload_key(args):
+    """Name of the workload for the PMC lookup: "c2" for the default shape (BASELINE config C2, dense
+    regime), otherwise a key no committed summary carries -- traffic measured on one shape is never
+    quoted for another."""
+    default = (args.height == 800 and args.width == 800 and args.samples == 128 and args.levels == 16 and
+               args.channels == 2 and args.log2_table == 19 and args.chunk == 65536 and args.rays == 0 and
+               args.regime == "dense")
+    if default:
+        return "c2"
+    return "%dx%d_S%d_L%d_F%d_T%d_chunk%d_rays%d_%s" % (
+        args.height, args.width, args.samples, args.levels, args.channels, args.log2_table, args.chunk,
+        args.rays, args.regime)
+
+
 def pmc_traffic(op, workload_key="c2"):
     """(HBM-side bytes per launch of `op`, provenance) from the newest committed rocprofv3 --pmc
     summary for this workload (profiles/r*_pmc_traffic*.json, made by tools/pmc_summary.py from
@@ -672,7 +686,7 @@ def main():
         roofline = None
         if dom:
             a = kernels[dom]["achieved_GBs"]
-            traffic, traffic_src = pmc_traffic(dom)
+            traffic, traffic_src = pmc_traffic(dom, workload_key(args))
             roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": traffic,
                         "traffic_source": traffic_src,

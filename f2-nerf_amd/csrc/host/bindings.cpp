@@ -9,6 +9,7 @@
 #include "points_sampler.hpp"
 #include "ragged_ops.hpp"
 #include "rays.hpp"
+#include "scene_files.hpp"
 #include "renderer.hpp"
 #include "sh_shader.hpp"
 
@@ -266,6 +267,34 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         return h;
       },
       "FusedAdam over the same groups: one kernel per parameter, emits the table's f16 shadow");
+
+  // ---- scene files: cams_meta.tsv, scene normalisation, inference_params.yaml
+  m.def("read_cams_meta", [](const std::string & path) {
+    f2n::CamsMeta c = f2n::read_cams_meta(path);
+    return py::make_tuple(c.poses, c.intrinsics, c.dist_params, c.bounds);
+  });
+  m.def("normalize_scene", [](const torch::Tensor & poses) {
+    f2n::SceneNormalisation n = f2n::normalize_scene(poses);
+    return py::make_tuple(n.poses, n.center, n.radius);
+  });
+  m.def(
+    "save_inference_params",
+    [](const std::string & dir, int n_images, int height, int width, const torch::Tensor & intrinsic,
+       const torch::Tensor & center, float radius) {
+      f2n::InferenceParams p;
+      p.n_images = n_images;
+      p.height = height;
+      p.width = width;
+      p.intrinsic = intrinsic;
+      p.normalizing_center = center;
+      p.normalizing_radius = radius;
+      f2n::save_inference_params(dir, p);
+    });
+  m.def("load_inference_params", [](const std::string & dir) {
+    f2n::InferenceParams p = f2n::load_inference_params(dir);
+    return py::make_tuple(
+      p.n_images, p.height, p.width, p.intrinsic, p.normalizing_center, p.normalizing_radius);
+  });
 
   py::class_<AdamHandle>(m, "Adam")
     .def("step", [](AdamHandle & h) { h.opt->step(); }, py::call_guard<py::gil_scoped_release>())

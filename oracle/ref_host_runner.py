@@ -6,7 +6,10 @@ computed.  TEST INFRASTRUCTURE: called by tests/test_gpu_ref_host.py.
   python oracle/ref_host_runner.py in.pt out.pt
 
 in.pt : {params: {name: tensor}, rays_o, rays_d, emb_idx, gt, seed, train, var_weight,
-         image: optional {pose [3,4], intrinsic [3,3], h, w, batch}}
+         image: optional {pose [3,4], intrinsic [3,3], h, w, batch},
+         save_checkpoint: optional path -- torch::save(renderer_, path) as train_manager.cpp:132-136,
+         load_checkpoint: optional path -- torch::load into a fresh Renderer as localizer.cpp:37-39
+                          (then `params` is ignored)}
 out.pt: {colors, depths, weights, idx_start_end, loss, mse, grads: {name: tensor}, image: (c, z)}
 
 TRAIN: the reference draws its step noise and background itself (src/points_sampler.cpp:35,
@@ -33,10 +36,15 @@ def main(path_in, path_out):
     ren = M.Renderer(n_images)
     params = ren.named_parameters()
     assert set(params) == set(d["params"]), (sorted(params), sorted(d["params"]))
-    with torch.no_grad():
-        for k, v in d["params"].items():
-            assert tuple(params[k].shape) == tuple(v.shape), k
-            params[k].copy_(v.to(dev))
+    if d.get("load_checkpoint"):
+        ren.load(d["load_checkpoint"])
+    else:
+        with torch.no_grad():
+            for k, v in d["params"].items():
+                assert tuple(params[k].shape) == tuple(v.shape), k
+                params[k].copy_(v.to(dev))
+    if d.get("save_checkpoint"):
+        ren.save(d["save_checkpoint"])
     to = lambda x: x.to(dev)
     out = {}
     emb = to(d["emb_idx"]) if d["train"] else torch.empty(0, dtype=torch.int32, device=dev)

@@ -36,6 +36,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         return out;
       })
     .def("zero_grad", [](Renderer & r) { r.zero_grad(); })
+    // src/main_functions/train_manager.cpp:132-136 / src/localizer.cpp:37-39
+    .def("save", [](std::shared_ptr<Renderer> r, const std::string & path) { torch::save(r, path); })
+    .def("load", [](std::shared_ptr<Renderer> r, const std::string & path) { torch::load(r, path); })
     .def(
       "render",
       [](Renderer & r, const Tensor & o, const Tensor & d, const Tensor & emb, bool train) {

@@ -202,3 +202,43 @@ def test_reference_renderer_validate_and_image(host, dev, tmp_path):
     assert tuple(ref_img.shape) == (h, w, 3)
     _close(img.cpu(), ref_img, 1e-4)
     _close(dep.cpu(), ref_dep, 1e-4)
+
+
+def test_checkpoint_written_by_the_reference_loads_here_and_back(host, dev, tmp_path):
+    """SURVEY 8(f) rank 3: `renderer.pt` as the reference writes it (torch::save of ITS module tree,
+    src/main_functions/train_manager.cpp:132-136) loads into this repository's Renderer with
+    torch::load, and a checkpoint written here loads into the reference's Renderer
+    (src/localizer.cpp:37-39) -- same registered names, shapes and dtypes on disk -- and both render
+    the same image."""
+    E, n_rays, S = 4, 16, 1024
+    g = torch.Generator().manual_seed(31)
+    torch.manual_seed(31)
+    oracle = R.Renderer(E, L=16, F=2, log2_T=19, S=S, step=1.0 / 256, gen=g, feat_init="trained")
+    with torch.no_grad():
+        oracle.scene_field.mlp.bias[0] = 6.0
+    o = torch.randn(n_rays, 3, generator=g) * 0.25
+    d = torch.randn(n_rays, 3, generator=g)
+    none_i, none_f = torch.zeros(0, dtype=torch.int32), torch.zeros(0)
+    ref_ckpt = str(tmp_path / "renderer_ref.pt")
+    ref = _run_reference(tmp_path, dict(params=_params_of(oracle), rays_o=o, rays_d=d, emb_idx=none_i,
+                                        gt=none_f, seed=1, train=False, var_weight=0.0, image=None,
+                                        save_checkpoint=ref_ckpt))
+    assert os.path.getsize(ref_ckpt) > 64 << 20          # the 64 MiB f32 table is in there
+    hr = host.Renderer(E, n_levels=16, n_channels=2, log2_table=19, max_samples=S, step=1.0 / 256)
+    hr.load(ref_ckpt)
+    for k, v in _params_of(oracle).items():
+        assert torch.equal(hr.named_parameters()[k].detach().cpu(), v), k
+    with torch.no_grad():
+        colors, depths = hr.render_all_rays(o.to(dev), d.to(dev), 16)
+    _close(colors.cpu(), ref["colors"], 1e-4)
+    # and the other direction: modify a parameter here, save, let the reference load and render
+    with torch.no_grad():
+        hr.named_parameters()["scene_field.mlp.bias"][0] = 5.0
+        colors2, _ = hr.render_all_rays(o.to(dev), d.to(dev), 16)
+    our_ckpt = str(tmp_path / "renderer_ours.pt")
+    hr.save(our_ckpt)
+    ref2 = _run_reference(tmp_path, dict(params=_params_of(oracle), rays_o=o, rays_d=d, emb_idx=none_i,
+                                         gt=none_f, seed=1, train=False, var_weight=0.0, image=None,
+                                         load_checkpoint=our_ckpt))
+    _close(colors2.cpu(), ref2["colors"], 1e-4)
+    assert float((ref2["colors"] - ref["colors"]).abs().max()) > 1e-4   # the edit really travelled
