@@ -47,9 +47,9 @@ constexpr int kCombinePaysAt = 4500;       // ... or records saved per tile-leve
 constexpr int kCombineDenseTile = 6000;    // level 0 is tried when the tile has this many non-zero
                                            // contributions (of 8192): that is where plain binning
                                            // overflows its queues at the coarse levels
-constexpr int kSplitBlock = 512;       // pass B: two workgroups per CU
-constexpr int kSplitQueueWords = 16384;  // 64 KiB
-constexpr int kSplitRegions = 4;       // regions a wave of pass B ingests per round
+constexpr int kSplitBlock = 512;       // pass B: four workgroups per CU (it is latency-bound)
+constexpr int kSplitQueueWords = 9216;   // 36 KiB: four workgroups per CU
+constexpr int kSplitRegions = 2;       // regions a wave of pass B ingests per round
 constexpr int kMaxBuckets = 64;
 constexpr int kMaxLog2Sub = 6;
 
@@ -208,7 +208,9 @@ struct BinArgs
   uint32_t * stats;  // optional [L][4] u32 counters (tools/ab_hash_bwd.py), else NULL
 };
 
-template <int F, bool POW2>
+// SAT: sum the saturated cell (0,0,0) in LDS (tables that take the split pass); a template
+// parameter so that the single-level kernel keeps its code and registers exactly.
+template <int F, bool POW2, bool SAT>
 __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
   const float * __restrict__ pts, const int32_t * __restrict__ primes,
   const float * __restrict__ bias, const float * __restrict__ mul,
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
   auto comb_index = [](uint32_t slot, int k) { return (uint32_t)k * (kSlots + (F > 1 ? 1u : 0u)) + slot; };
   __shared__ __attribute__((aligned(16))) uint32_t queue[kBinQueueWords];
   __shared__ uint32_t qcount[kMaxBuckets];
+  __shared__ unsigned long long sat_acc[8 * F];  // cell (0,0,0): exact sums per corner and channel
   // [0] combine the coming level, [1] non-zero contributions of this level, [2] lanes of the tile
   // whose level-0 cell equals the previous sample's, [3] lanes that have a previous sample,
   // [4] mean run length at level 0 (x256), [5] records that overflowed this level
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
     __syncthreads();  // the previous level's flush has read the queues and counters
     const bool comb = comb_state[0] != 0u;
     if (threadIdx.x < kMaxBuckets) qcount[threadIdx.x] = 0u;
+    if (SAT && threadIdx.x < 8 * F) sat_acc[threadIdx.x] = 0ull;
     if (threadIdx.x == 0) comb_state[1] = 0u;
     __syncthreads();
 
@@ -507,6 +511,15 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
     } else {
       // ---- plain binning: one record per (point, corner).  When the queues cannot hold a whole
       // tile-level (F = 8 with 64 buckets) the tile's points take turns in `groups` rounds.
+      //
+      // One cell is special: points whose three scaled coordinates are all negative saturate to
+      // cell (0,0,0) (quirk Q1) -- at the finest levels that is ~9 % of uniformly spread points, all on
+      // the SAME eight rows, which then carry 20x the mean slice load: their records overflow every
+      // queue downstream and end as same-address global atomics (config C5: 1.3-3 % of a fine level's
+      // records, but most of the split pass's time).  Their contributions are summed exactly in LDS
+      // instead and leave as a handful of f16 pieces per tile and level.  (Only for tables that take the
+      // split pass: the extra barrier and checks cost the single-level bench workload 0.3 ms per chunk,
+      // and there a hot slice merely fills its regions.)
       for (int g = 0; g < a.groups; g++) {
         if (g > 0) {
           __syncthreads();  // the previous round's flush has read the queues
@@ -516,15 +529,71 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
         if (active && (int)((threadIdx.x * (unsigned)a.groups) / kBinBlock) == g) {
           const LevelParams lp = load_level(primes, bias, mul, l);
           corner_rows_and_weights<POW2>(x, y, z, lp, a.T, row, w);
+          const bool sat3 = SAT && fmaf(x, lp.mul, lp.bx) < 0.f && fmaf(y, lp.mul, lp.by) < 0.f &&
+                            fmaf(z, lp.mul, lp.bz) < 0.f;
 #pragma unroll
           for (int d = 0; d < 8; d++) {
             uint32_t val[VW];
             corner_value(d, val);
             if (val_all_zero<F>(val)) continue;
+            if constexpr (SAT) {
+              bool finite = true;
+#pragma unroll
+              for (int k = 0; k < F; k++) finite &= !f16_bits_nonfinite(val_channel_bits<F>(val, k));
+              if (sat3 && finite) {
+#pragma unroll
+                for (int k = 0; k < F; k++) {
+                  const uint32_t hb = val_channel_bits<F>(val, k);
+                  if (hb & 0x7fffu)
+                    atomicAdd(&sat_acc[d * F + k], (unsigned long long)f16_bits_to_fixed(hb));
+                }
+                continue;
+              }
+            }
             enqueue(row[d], val, a.qcap);
           }
         }
         __syncthreads();
+        if (SAT && g == a.groups - 1) {
+          // corner d of cell (0,0,0): thread d re-expresses its F sums as f16 pieces
+          if (threadIdx.x < 8) {
+            const int d = (int)threadIdx.x;
+            long long S[F];
+            bool nz = false;
+#pragma unroll
+            for (int k = 0; k < F; k++) {
+              S[k] = (long long)sat_acc[d * F + k];
+              nz |= (S[k] != 0);
+            }
+            if (nz) {
+              const LevelParams lp = load_level(primes, bias, mul, l);
+              const uint32_t r = wrap_row<POW2>(
+                ((d & 4) ? lp.pa : 0u) ^ ((d & 2) ? lp.pb : 0u) ^ ((d & 1) ? lp.pc : 0u), a.T);
+              for (int piece = 0; piece < kMaxPieces && nz; piece++) {
+                uint32_t val[VW];
+#pragma unroll
+                for (int j = 0; j < VW; j++) val[j] = 0u;
+                nz = false;
+#pragma unroll
+                for (int k = 0; k < F; k++) {
+                  const uint32_t hb = take_f16_piece(S[k]);
+                  val[F >= 2 ? k / 2 : 0] |= (k & 1) ? (hb << 16) : hb;
+                  nz |= (S[k] != 0);
+                }
+                enqueue(r, val, a.qcap);
+              }
+              if (nz) {
+#pragma unroll
+                for (int k = 0; k < F; k++)
+                  if (S[k] != 0)
+                    atomicAdd(
+                      gbase + (int64_t)r * F + k,
+                      (float)((double)S[k] * ((double)a.inv_scale * (1.0 / 16777216.0))));
+              }
+            }
+          }
+          __syncthreads();
+        }
         flush(a.qcap, tile * a.groups + g);
       }
     }
@@ -546,6 +615,7 @@ struct SplitArgs
   int64_t n_tiles_g;  // regions per (level, bucket) of pass A
   float inv_scale;
   int n_buckets, bshift, log2_sub, qcap, n_slices, tiles_per_part, n_parts, cap2;
+  uint32_t * stats;  // optional [L][4] counters: [3] += records that overflowed a queue or a run
 };
 
 template <int F>
@@ -599,10 +669,12 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
         if ((uint32_t)(lane + 64 * h) < cnt[u]) {
           const uint32_t sub = r[u] / kRows, local = r[u] & (kRows - 1u);
           const uint32_t slot = atomicAdd(&qcount[sub], 1u);
-          if (slot < (uint32_t)Q)
+          if (slot < (uint32_t)Q) {
             store_record<F>(queue + (size_t)sub * Q * KW, Q, slot, local, v[u]);
-          else
+          } else {
             apply_record_atomic<F>(gbase, row0 + r[u], v[u], a.inv_scale);
+            if (a.stats) atomicAdd(a.stats + 4 * l + 3, 1u);
+          }
         }
       }
     }
@@ -619,6 +691,7 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
           uint32_t rr, vv[VW];
           load_record<F>(queue + (size_t)sub * Q * KW, Q, i, rr, vv);
           apply_record_atomic<F>(gbase, row0 + (uint32_t)sub * kRows + rr, vv, a.inv_scale);
+          if (a.stats) atomicAdd(a.stats + 4 * l + 2, 1u);
         }
       }
       if (lane == 0) {
@@ -1040,16 +1113,19 @@ extern "C" int f2n_hash_bwd_binned(
     ba.combine = combine;
     ba.stats = g_bin_stats.load(std::memory_order_relaxed);
     const int64_t tiles_g = tiles * pl.groups;
+#define F2N_BIN_LAUNCH(P2, SAT)                                                                     \
+  hipLaunchKernelGGL(                                                                              \
+    (hash_bwd_bin_kernel<FF, P2, SAT>), grid_a, block_a, 0, s, pts + 3 * p0, primes, bias, mul,    \
+    grad_out + p0 * g_ld_point, table_grad, a_records, a_counts, ba)
     const dim3 grid_a((unsigned)tiles), block_a(kBinBlock);
     F2N_DISPATCH_F(F, {
-      if (p2)
-        hipLaunchKernelGGL(
-          (hash_bwd_bin_kernel<FF, true>), grid_a, block_a, 0, s, pts + 3 * p0, primes, bias, mul,
-          grad_out + p0 * g_ld_point, table_grad, a_records, a_counts, ba);
-      else
-        hipLaunchKernelGGL(
-          (hash_bwd_bin_kernel<FF, false>), grid_a, block_a, 0, s, pts + 3 * p0, primes, bias, mul,
-          grad_out + p0 * g_ld_point, table_grad, a_records, a_counts, ba);
+      if (pl.log2_sub > 0) {
+        if (p2) F2N_BIN_LAUNCH(true, true);
+        else F2N_BIN_LAUNCH(false, true);
+      } else {
+        if (p2) F2N_BIN_LAUNCH(true, false);
+        else F2N_BIN_LAUNCH(false, false);
+      }
       if (pl.log2_sub == 0) {
         const dim3 grid_c((unsigned)pl.n_slices, (unsigned)L);
         if (disjoint)
@@ -1078,6 +1154,7 @@ extern "C" int f2n_hash_bwd_binned(
         sa.tiles_per_part = pl.tiles_per_part;
         sa.n_parts = pl.n_parts;
         sa.cap2 = pl.cap2;
+        sa.stats = g_bin_stats.load(std::memory_order_relaxed);
         const dim3 grid_b((unsigned)pl.n_buckets, (unsigned)L, (unsigned)pl.n_parts);
         hipLaunchKernelGGL((hash_bwd_split_kernel<FF>), grid_b, dim3(kSplitBlock), 0, s, sa);
         const dim3 grid_c((unsigned)pl.n_slices, (unsigned)L);
@@ -1091,6 +1168,7 @@ extern "C" int f2n_hash_bwd_binned(
             b_counts, table_grad, T, level_stride, inv, pl.n_slices, pl.n_parts, pl.cap2);
       }
     })
+#undef F2N_BIN_LAUNCH
     if (hipGetLastError() != hipSuccess) return F2N_E_LAUNCH;
   }
   return F2N_OK;

@@ -141,6 +141,8 @@ def main():
             if int(st[1, 3]):
                 print("    %d tiles, %.0f non-zero level-0 contributions per tile" % (int(st[1, 3]), int(st[0, 3]) / int(st[1, 3])))
             for l in range(L):
+                if not int(st[l, 0]) and (int(st[l, 2]) or int(st[l, 3])):
+                    print("    level %2d: split pass overflow: %d records past a queue, %d past a run" % (l, int(st[l, 3]), int(st[l, 2])))
                 if int(st[l, 0]):
                     print("    level %2d: %6d tiles combined, %5.0f non-zero contributions -> %5.0f records per tile"
                           % (l, int(st[l, 0]), int(st[l, 1]) / int(st[l, 0]), int(st[l, 2]) / int(st[l, 0])))
