@@ -93,7 +93,7 @@ __global__ __launch_bounds__(F2N_BLOCK) void hash_fwd_raytile_kernel(
   const float * __restrict__ pts, const uint16_t * __restrict__ table,
   const int32_t * __restrict__ primes, const float * __restrict__ bias,
   const float * __restrict__ mul, float * __restrict__ out, int n_rays, int S, uint32_t T,
-  int64_t level_stride)
+  int64_t level_stride, int walk)
 {
   static_assert(F2N_BLOCK == 256 && SAMPLES % 16 == 0, "4 waves, float4 runs");
   constexpr int RAYS = 64, kPitch = SAMPLES + 4, kPPitch = 3 * SAMPLES + 1;
@@ -113,17 +113,42 @@ __global__ __launch_bounds__(F2N_BLOCK) void hash_fwd_raytile_kernel(
   }
   const LevelParams lp = load_level(primes, bias, mul, l);
   __syncthreads();
+  // Which way do the 64 lanes of a gather walk the tile?  The cost of a gather instruction is its
+  // number of distinct 128-byte lines (tools/probes/gather_policy.hip), i.e. of distinct cells:
+  //   across  lane = ray, all at one sample index: neighbouring pixels of a view sit 1-4 fine cells
+  //           apart at one depth (image-ordered batches, the renderer's whole-view chunks);
+  //   along   lane = consecutive samples of one ray (64 / SAMPLES rays per instruction): the
+  //           reference's 1024 steps of 1/256 put up to 32 consecutive samples in one coarse cell
+  //           (random training rays: neighbouring rays share nothing).
+  // Decided per tile from its own points: the walk with the smaller extent touches fewer cells.
+  bool along;
+  {
+    // extent of the tile across its rays at the middle sample, and along its first ray
+    constexpr int m = SAMPLES / 2;
+    const float ex = ptile[RAYS - 1][3 * m] - ptile[0][3 * m],
+                ey = ptile[RAYS - 1][3 * m + 1] - ptile[0][3 * m + 1],
+                ez = ptile[RAYS - 1][3 * m + 2] - ptile[0][3 * m + 2];
+    const float sx = ptile[0][3 * (SAMPLES - 1)] - ptile[0][0],
+                sy = ptile[0][3 * (SAMPLES - 1) + 1] - ptile[0][1],
+                sz = ptile[0][3 * (SAMPLES - 1) + 2] - ptile[0][2];
+    // across only when the rays are clearly closer together than a ray's samples are long (image-
+    // ordered rays, jittered or not: 0.1-0.3 against 1.0 at 128 samples; random rays: 1.5 against 1.0)
+    along = !(4.f * (ex * ex + ey * ey + ez * ez) < sx * sx + sy * sy + sz * sz);
+    if (walk) along = (walk == 2);
+  }
+  constexpr int kRaysPerIter = 64 / SAMPLES;  // along: rays one wave instruction covers
 #pragma unroll
   for (int j = 0; j < SAMPLES / 4; j++) {
-    const int ks = j * 4 + wave;
-    const float x = ptile[lane][3 * ks], y = ptile[lane][3 * ks + 1], z = ptile[lane][3 * ks + 2];
+    const int ks = along ? (lane % SAMPLES) : (j * 4 + wave);
+    const int ray = along ? ((j * 4 + wave) * kRaysPerIter + lane / SAMPLES) : lane;
+    const float x = ptile[ray][3 * ks], y = ptile[ray][3 * ks + 1], z = ptile[ray][3 * ks + 2];
     uint32_t row[8];
     float w[8];
     corner_rows_and_weights<POW2>(x, y, z, lp, T, row, w);
     float acc[F];
     gather_blend<F>(table + level_stride * l, row, w, acc);
 #pragma unroll
-    for (int k = 0; k < F; k++) tile[k][lane][ks] = round_f16(acc[k]);
+    for (int k = 0; k < F; k++) tile[k][ray][ks] = round_f16(acc[k]);
   }
   __syncthreads();
   // RAYS x (SAMPLES / 4) float4 per channel, SAMPLES / 16 per thread
@@ -421,6 +446,7 @@ extern "C" int f2n_hash_fwd_raytile(
   if (reinterpret_cast<uintptr_t>(table_f16) % (2u * F)) return F2N_E_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(out_cm) & 15u) return F2N_E_INVALID_ARG;
   if (n == 0) return F2N_OK;
+  const int walk = f2n_get_option(F2N_OPT_RAYTILE_WALK);
   const int want = f2n_get_option(F2N_OPT_RAYTILE);  // samples per tile: 16 | 32 (measurements)
   const int ts = (want == 16) ? 16 : (S % 32 == 0 ? 32 : 16);
   const int64_t tiles = (int64_t)f2n_div_up(n_rays, 64) * (S / ts);
@@ -431,7 +457,7 @@ extern "C" int f2n_hash_fwd_raytile(
 #define F2N_RT_LAUNCH(P2, SS)                                                                      \
   hipLaunchKernelGGL(                                                                              \
     (hash_fwd_raytile_kernel<FF, P2, SS>), grid, block, 0, s, pts, table_f16, primes, bias, mul,   \
-    out_cm, n_rays, S, T, level_stride)
+    out_cm, n_rays, S, T, level_stride, walk)
   F2N_DISPATCH_F(F, {
     if (p2) {
       if (ts == 16) F2N_RT_LAUNCH(true, 16);

@@ -44,6 +44,7 @@ def main():
     capi = importlib.import_module("f2-nerf_amd").capi
     dev = torch.device("cuda:0")
     cfg = {"c2": (16, 2, 19, None, 65536 * 128), "c1": (4, 2, 19, None, 65536 * 64),
+           "c4": (16, 2, 19, None, 512 * 1024),
            "c5": (16, 8, 22, "disjoint", 1 << 24)}[args.config]
     L, F, log2_T, stride_mode, n = cfg
     if args.n:
@@ -60,12 +61,13 @@ def main():
     mul = torch.tensor([2.0 ** (7.0 * l / max(L - 1, 1) + 3.0) for l in range(L)], device=dev)
     if args.points == "rays":
         # consecutive samples along rays (what the renderer feeds): 128 per ray, step 1/32
-        S = 128
+        # (config c4: the reference's 1024 steps of 1/256)
+        S = 1024 if args.config == "c4" else 128
         R = n // S
         o = torch.randn(R, 1, 3, device=dev, generator=g) * 0.3
         d = torch.randn(R, 1, 3, device=dev, generator=g)
         d = d / d.norm(dim=-1, keepdim=True)
-        t = (torch.arange(1, S + 1, device=dev).float() / 32).reshape(1, S, 1)
+        t = (torch.arange(1, S + 1, device=dev).float() * (4.0 / S)).reshape(1, S, 1)
         p = (o + d * t).reshape(-1, 3)
         nrm = p.norm(dim=1, keepdim=True)
         pts = torch.where(nrm <= 1, p, (2 - 1 / nrm) * p / nrm).contiguous()
@@ -100,10 +102,14 @@ def main():
                                              None, n, L, F, T, stride), args.reps)
         print("  %-28s %8.3f ms (best %8.3f)  %7.1f GB/s algorithmic" % (name, med, best, n * bytes_fwd / med / 1e6))
     if args.points in ("rays", "view") and n % 128 == 0:
-        med, best = timeit(lambda: capi.call("hash_fwd_raytile", pts, table16, primes, bias, mul, out_cm,
-                                             n // 128, 128, L, F, T, stride), args.reps)
-        print("  %-28s %8.3f ms (best %8.3f)  %7.1f GB/s algorithmic" %
-              ("fwd ray-tile [C,n]", med, best, n * bytes_fwd / med / 1e6))
+        S_rt = 1024 if args.config == "c4" else 128
+        for walk, name in ((0, "auto"), (1, "across rays"), (2, "along a ray")):
+            capi.set_option("RAYTILE_WALK", walk)
+            med, best = timeit(lambda: capi.call("hash_fwd_raytile", pts, table16, primes, bias, mul, out_cm,
+                                                 n // S_rt, S_rt, L, F, T, stride), args.reps)
+            print("  %-28s %8.3f ms (best %8.3f)  %7.1f GB/s algorithmic" %
+                  ("fwd ray-tile, " + name, med, best, n * bytes_fwd / med / 1e6))
+        capi.set_option("RAYTILE_WALK", 0)
     if args.fwd_only:
         return
     grad_rm = torch.randn(n, C, device=dev, generator=g) * 1e-3
