@@ -123,17 +123,19 @@ __global__ __launch_bounds__(F2N_BLOCK) void hash_fwd_raytile_kernel(
   // Decided per tile from its own points: the walk with the smaller extent touches fewer cells.
   bool along;
   {
-    // extent of the tile across its rays at the middle sample, and along its first ray
+    // Distinct cells of size c touched by one gather: across ~ (e / c + 1) for rays strung along a
+    // pixel row of extent e, times the depth cloud the TRAIN jitter adds (neighbouring rays then sit
+    // a random e1 apart at one sample index); along ~ 2 rays x (s / c + 1) for a ray segment of
+    // length s.  Across wins when e + 8 e1 < 2 s: image-ordered batches, jittered (0.15 + 8 x 0.07
+    // against 2 x 1.0 at 128 samples) or not, near or far; random rays (e, e1 ~ 1.5) walk along.
     constexpr int m = SAMPLES / 2;
-    const float ex = ptile[RAYS - 1][3 * m] - ptile[0][3 * m],
-                ey = ptile[RAYS - 1][3 * m + 1] - ptile[0][3 * m + 1],
-                ez = ptile[RAYS - 1][3 * m + 2] - ptile[0][3 * m + 2];
-    const float sx = ptile[0][3 * (SAMPLES - 1)] - ptile[0][0],
-                sy = ptile[0][3 * (SAMPLES - 1) + 1] - ptile[0][1],
-                sz = ptile[0][3 * (SAMPLES - 1) + 2] - ptile[0][2];
-    // across only when the rays are clearly closer together than a ray's samples are long (image-
-    // ordered rays, jittered or not: 0.1-0.3 against 1.0 at 128 samples; random rays: 1.5 against 1.0)
-    along = !(4.f * (ex * ex + ey * ey + ez * ez) < sx * sx + sy * sy + sz * sz);
+    auto dist = [&](int ra, int sa, int rb, int sb) {
+      const float dx = ptile[ra][3 * sa] - ptile[rb][3 * sb], dy = ptile[ra][3 * sa + 1] - ptile[rb][3 * sb + 1],
+                  dz = ptile[ra][3 * sa + 2] - ptile[rb][3 * sb + 2];
+      return sqrtf(dx * dx + dy * dy + dz * dz);
+    };
+    const float e = dist(RAYS - 1, m, 0, m), e1 = dist(1, m, 0, m), sl = dist(0, SAMPLES - 1, 0, 0);
+    along = !(e + 8.f * e1 < 2.f * sl);
     if (walk) along = (walk == 2);
   }
   constexpr int kRaysPerIter = 64 / SAMPLES;  // along: rays one wave instruction covers
