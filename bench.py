@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="kernel route for A/B measurements (f2n_set_option), e.g. BWD_COMBINE=1; "
                          "recorded in the JSON line")
+    ap.add_argument("--debug-bin-stats", action="store_true",
+                    help="print the binned backward's per-level counters of the timed steps on stderr")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / collective check without a GPU: every rank joins the "
                          "process group (use --backend gloo), shards a synthetic error vector, runs the "
@@ -611,6 +613,11 @@ def main():
     for s in range(args.warmup):
         run_step(views[s])
     barrier()
+    bin_counters = None
+    if args.debug_bin_stats and rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bin_stats
+        bin_counters = bin_stats.enable(pkg.capi.lib().cdll, dev)
     H.kernel_timer_enable(True)
     H.kernel_timer_collect()
     t0 = time.perf_counter()
@@ -623,6 +630,8 @@ def main():
     elapsed = time.perf_counter() - t0
     H.kernel_timer_enable(False)
     timings = H.kernel_timer_collect()
+    if bin_counters is not None:
+        bin_stats.report(pkg.capi.lib().cdll, bin_counters, L, out=sys.stderr)
 
     # optimiser step: outside the headline (BASELINE.md excludes it) but reported next to it
     opt_ms = {}

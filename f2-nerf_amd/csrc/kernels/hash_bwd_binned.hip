@@ -236,13 +236,13 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
   // channels of level l+1 are requested before level l is processed -- with a 128 KiB LDS stage only
   // one workgroup fits a CU, so nothing else would hide that load.
   const int64_t tile = blockIdx.x;
-  const int64_t p = tile * kBinBlock + threadIdx.x;
-  const bool valid = p < a.n;
-  const int64_t pc = valid ? p : a.n - 1;
-  const float x = pts[3 * pc + 0], y = pts[3 * pc + 1], z = pts[3 * pc + 2];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
   constexpr int kWaves = kBinBlock / 64;
+  // (not const: a tile that combines re-deals its points to the threads below)
+  bool valid = tile * kBinBlock + threadIdx.x < a.n;
+  int64_t pc = valid ? tile * kBinBlock + threadIdx.x : a.n - 1;
+  float x = pts[3 * pc + 0], y = pts[3 * pc + 1], z = pts[3 * pc + 2];
   const uint32_t bmask = (1u << a.bshift) - 1u;
   const int64_t n_tiles_g = a.n_tiles * a.groups;
 
@@ -311,6 +311,24 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
         atomicAdd(a.stats + 3, comb_state[1]);
         atomicAdd(a.stats + 7, 1u);
       }
+    }
+    __syncthreads();
+    if (comb_state[0] != 0u) {
+      // A tile that combines is (part of) a densely sampled ray: runs of consecutive samples share
+      // a cell, so the 64 lanes of one LDS atomic below would hit a handful of addresses and the LDS
+      // serialises them (32 samples per level-0 cell at the reference's 1024 steps of 1/256: 19 us per
+      // tile and level instead of 4).  Deal the samples out 16 apart instead -- lane l of wave w takes
+      // sample 16 l + w -- so that one instruction's lanes spread over the whole tile.  The order of
+      // the points means nothing to the sums; the price is uncoalesced (but cached, and prefetched a
+      // level ahead) gradient loads.
+      const int64_t p = tile * kBinBlock + (int64_t)(lane * kWaves + wave);
+      valid = p < a.n;
+      pc = valid ? p : a.n - 1;
+      x = pts[3 * pc + 0];
+      y = pts[3 * pc + 1];
+      z = pts[3 * pc + 2];
+#pragma unroll
+      for (int k = 0; k < F; k++) g_cur[k] = grad_out[pc * a.g_ld_point + (int64_t)k * a.g_ld_chan];
     }
   }
 
@@ -830,16 +848,21 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
   // lanes and a whole batch is in flight at once -- regions of a few records each (sparse
   // gradients) cost no more than their records.
   uint32_t * woff = &batch_off[wave][0];
-  constexpr int kFlat = 8;  // 64-record loads in flight per wave
-  for (int64_t t0 = (int64_t)wave * 64; t0 < n_tiles; t0 += (int64_t)kWaves * 64) {
-    const uint32_t my_cnt = (t0 + lane < n_tiles) ? min(counts[t0 + lane], (uint32_t)qcap) : 0u;
+  constexpr int kFlat = 16;  // 64-record loads in flight per wave
+  // (fewer tiles per batch when there are few tiles -- a 512-ray training batch has 512 -- so that
+  // all sixteen waves have one)
+  int bt = 64;
+  while (bt > 8 && (int64_t)bt * kWaves > n_tiles) bt >>= 1;
+  for (int64_t t0 = (int64_t)wave * bt; t0 < n_tiles; t0 += (int64_t)kWaves * bt) {
+    const uint32_t my_cnt =
+      (lane < bt && t0 + lane < n_tiles) ? min(counts[t0 + lane], (uint32_t)qcap) : 0u;
     const uint32_t incl = (uint32_t)wave_incl_scan_i32((int)my_cnt);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (total > 64u * 40u) {
       // well-filled regions (dense gradients): one 64-lane load per region and 64 records, several
       // regions in flight; the search below would cost more than the idle tail lanes
       constexpr int kRegions = 8;
-      const int n_here = (int)min((int64_t)64, n_tiles - t0);
+      const int n_here = (int)min((int64_t)bt, n_tiles - t0);
       const int n_half = (qcap + 63) / 64;
       for (int j0 = 0; j0 < n_here; j0 += kRegions) {
         uint32_t cnt[kRegions];

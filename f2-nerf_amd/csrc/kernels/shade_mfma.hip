@@ -560,8 +560,43 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
     wave_lds_sync();
   }
 
-  // ---- flush this wave's accumulators
+  // ---- flush the accumulators: the four waves' sums meet in wave 0 first (its LDS tile regions are
+  // free now), so a workgroup sends one set of atomics instead of four -- with few strides per wave
+  // (a 512-ray training batch: 8) the 4 160 atomics of every wave on the same 2 400 addresses were a
+  // third of the kernel
   if (has_emb) flush_emb();
+  {
+    auto each_acc = [&](auto && fn) {
+      int i = 0;
+#pragma unroll
+      for (int M = 0; M < 4; M++) {
+#pragma unroll
+        for (int N = 0; N < 2; N++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc_w1[M][N][r] = fn(acc_w1[M][N][r], i++);
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc_w2[M][r] = fn(acc_w2[M][r], i++);
+        acc_b1[M] = fn(acc_b1[M], i++);
+      }
+#pragma unroll
+      for (int N = 0; N < kM6; N++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc_wh[N][r] = fn(acc_wh[N][r], i++);
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc_bh[r] = fn(acc_bh[r], i++);
+      acc_b2 = fn(acc_b2, i++);
+    };
+    static_assert((57 + 4 * kM6) * 64 <= S::kWaveFloats, "the accumulators fit a wave's tile region");
+    wave_lds_sync();
+    if (wave != 0) each_acc([&](float v, int i) { tile[i * 64 + lane] = v; return v; });
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < S::kWaves; w++) {
+      const float * other = lds_all + S::kWFloats + w * S::kWaveFloats;
+      each_acc([&](float v, int i) { return v + other[i * 64 + lane]; });
+    }
+  }
 #pragma unroll
   for (int M = 0; M < 4; M++) {
 #pragma unroll

@@ -13,6 +13,8 @@ import sys
 
 import torch
 
+import bin_stats
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -130,22 +132,9 @@ def main():
                   (name, label, ms, n * bytes_alg / ms / 1e6, need / 2 ** 30))
         if name == "current":
             capi.set_option("BWD_COMBINE", 0)
-            stats = torch.zeros(32, 4, dtype=torch.int32, device=dev)
-            lib.f2n_debug_bin_stats.argtypes = [ctypes.c_void_p]
-            lib.f2n_debug_bin_stats.restype = None
-            lib.f2n_debug_bin_stats(stats.data_ptr())
+            stats = bin_stats.enable(lib, dev)
             run()
-            torch.cuda.synchronize()
-            lib.f2n_debug_bin_stats(None)
-            st = stats.cpu()
-            if int(st[1, 3]):
-                print("    %d tiles, %.0f non-zero level-0 contributions per tile" % (int(st[1, 3]), int(st[0, 3]) / int(st[1, 3])))
-            for l in range(L):
-                if not int(st[l, 0]) and (int(st[l, 2]) or int(st[l, 3])):
-                    print("    level %2d: split pass overflow: %d records past a queue, %d past a run" % (l, int(st[l, 3]), int(st[l, 2])))
-                if int(st[l, 0]):
-                    print("    level %2d: %6d tiles combined, %5.0f non-zero contributions -> %5.0f records per tile"
-                          % (l, int(st[l, 0]), int(st[l, 1]) / int(st[l, 0]), int(st[l, 2]) / int(st[l, 0])))
+            bin_stats.report(lib, stats, L)
         del ws
 
 
