@@ -223,6 +223,8 @@ public:
         f2n::fptr(d_colors), f2n::fptr(d_depths), f2n::fptr(d_weights), d_logit.data_ptr<float>(),
         d_rgb.data_ptr<float>(), n_rays, 3.f, 1e-2f, f2n::current_stream(field_out)),
       "f2n_composite_bwd");
+    if (field_out.size(1) == 1)  // the fused path hands over the logit column alone
+      return {d_logit.unsqueeze(1), d_rgb, Tensor(), Tensor(), Tensor(), Tensor()};
     Tensor d_field = torch::zeros_like(field_out);
     d_field.select(1, 0).copy_(d_logit);
     return {d_field, d_rgb, Tensor(), Tensor(), Tensor(), Tensor()};

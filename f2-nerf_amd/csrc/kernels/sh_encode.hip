@@ -1,6 +1,6 @@
 // sh_encode.hip -- real spherical-harmonics direction encoding.
 // Replaces SHKernel<<<ceil(n/512),512>>> (reference src/sh_shader.cu:11-115); basis definition and
-// sign convention per that file (:32-50 for degree <= 4, the degree SHShader uses).
+// sign convention per that file (:32-102; degrees 1..8, SHShader uses 4) -- see sh_basis.hiph.
 //
 // One thread per direction.  Each thread owns a full degree^2-float output row (64 B at degree 4 =
 // one cache line), written with 16-byte stores.
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(F2N_BLOCK) void sh_encode_kernel(
 extern "C" int f2n_sh_encode(const float * dirs, float * out, int64_t n, int degree, void * stream)
 {
   if (!dirs || !out || n < 0 || degree < 1) return F2N_E_INVALID_ARG;
-  if (degree > 4) return F2N_E_UNSUPPORTED;
+  if (degree > 8) return F2N_E_UNSUPPORTED;  // the reference codes degrees up to 8 (:52-102)
   if (n == 0) return F2N_OK;
   if (reinterpret_cast<uintptr_t>(out) & 15u) return F2N_E_INVALID_ARG;
   const dim3 grid(f2n_div_up(n, F2N_BLOCK)), block(F2N_BLOCK);
@@ -44,7 +44,11 @@ extern "C" int f2n_sh_encode(const float * dirs, float * out, int64_t n, int deg
     case 1: hipLaunchKernelGGL(sh_encode_kernel<1>, grid, block, 0, s, dirs, out, n); break;
     case 2: hipLaunchKernelGGL(sh_encode_kernel<2>, grid, block, 0, s, dirs, out, n); break;
     case 3: hipLaunchKernelGGL(sh_encode_kernel<3>, grid, block, 0, s, dirs, out, n); break;
-    default: hipLaunchKernelGGL(sh_encode_kernel<4>, grid, block, 0, s, dirs, out, n); break;
+    case 4: hipLaunchKernelGGL(sh_encode_kernel<4>, grid, block, 0, s, dirs, out, n); break;
+    case 5: hipLaunchKernelGGL(sh_encode_kernel<5>, grid, block, 0, s, dirs, out, n); break;
+    case 6: hipLaunchKernelGGL(sh_encode_kernel<6>, grid, block, 0, s, dirs, out, n); break;
+    case 7: hipLaunchKernelGGL(sh_encode_kernel<7>, grid, block, 0, s, dirs, out, n); break;
+    default: hipLaunchKernelGGL(sh_encode_kernel<8>, grid, block, 0, s, dirs, out, n); break;
   }
   return f2n_launch_status();
 }

@@ -280,7 +280,7 @@ void f2no_div_inplace(float * x, int64_t n, float div)
 
 /* ---------------------------------------------------------------- SH encode (A6) -------------- */
 
-/* SHKernel: src/sh_shader.cu:11-103.  Real spherical-harmonics basis, degree<=4 -> 16 values.
+/* SHKernel: src/sh_shader.cu:11-103.  Real spherical-harmonics basis, degree <= 8 -> degree^2 values.
  * Products/sums follow the reference expressions; a*b+c forms use fmaf as nvcc would. */
 void f2no_sh_encode(const float * dirs, float * out, int64_t n, int degree)
 {
@@ -309,7 +309,42 @@ void f2no_sh_encode(const float * dirs, float * out, int64_t n, int degree)
     o[13] = 0.45704579946446572f * x * fmaf(-5.0f, z2, 1.0f);
     o[14] = 1.4453057213202769f * z * (x2 - y2);
     o[15] = 0.59004358992664352f * x * fmaf(3.0f, y2, -x2);
-    /* degree > 4 is coded in the reference (:52-102) but SHShader::DEGREE == 4 (sh_shader.hpp:20) */
+    if (degree <= 4) continue;
+    /* Bands 4..7 (degree 5..8): coded in the reference (:52-102) as expanded polynomials "based on
+     * the recurrence relations in appendix A1 of" Sloan's Stupid SH Tricks (:30), used by nothing
+     * (SHShader::DEGREE == 4, sh_shader.hpp:20).  Restated here from the definition those
+     * polynomials expand, in double precision:
+     *   out[l*l + l + m] = (-1)^m sqrt2(m) N(l,|m|) Q(l,|m|)(z) {Re, Im}((x + iy)^|m|)
+     * (same ordering and signs as bands 0..3 above).  tests/test_oracle_cpu.py checks this against
+     * the closed forms the reference's comments give for a dozen of the entries. */
+    {
+      double c[8], s[8];
+      c[0] = 1.0;
+      s[0] = 0.0;
+      for (int m = 1; m < degree; m++) {
+        c[m] = (double)x * c[m - 1] - (double)y * s[m - 1];
+        s[m] = (double)x * s[m - 1] + (double)y * c[m - 1];
+      }
+      for (int m = 0; m < degree; m++) {
+        double q2 = 0.0, q1 = 1.0;
+        for (int k = 1; k <= m; k++) q1 *= (double)(2 * k - 1);
+        for (int l = m; l < degree; l++) {
+          double q = q1;
+          if (l > m) {
+            q = ((2.0 * l - 1.0) * (double)z * q1 - (double)(l + m - 1) * q2) / (double)(l - m);
+            q2 = q1;
+            q1 = q;
+          }
+          if (l < 4) continue;
+          double ratio = 1.0;
+          for (int k = l - m + 1; k <= l + m; k++) ratio /= (double)k;
+          double nrm = sqrt((2.0 * l + 1.0) / (4.0 * 3.14159265358979323846) * ratio) * (m ? sqrt(2.0) : 1.0);
+          if (m & 1) nrm = -nrm;
+          o[l * l + l + m] = (float)(nrm * q * c[m]);
+          if (m > 0) o[l * l + l - m] = (float)(nrm * q * s[m]);
+        }
+      }
+    }
   }
 }
 

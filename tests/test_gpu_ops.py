@@ -328,6 +328,26 @@ def test_sh_encode(capi, dev, degree):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("degree", [5, 6, 7, 8])
+def test_sh_encode_high_degrees(capi, dev, degree):
+    """Bands 4..7 (coded in the reference, src/sh_shader.cu:52-102, used by nothing in it): the
+    kernel runs the f32 recurrences, the oracle the same definition in double -- tolerance 4e-6
+    absolute on values of magnitude <= 3 (a few f32 roundings of an 8-term recurrence); the first 16
+    columns stay bit-equal to the degree-4 result the renderer uses."""
+    g = torch.Generator().manual_seed(7)
+    d = torch.randn(30001, 3, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    d[:6] = torch.tensor([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [-1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]])
+    ref = K.sh_encode(d, degree)
+    out = torch.empty(d.shape[0], degree * degree, device=dev)
+    capi.call("sh_encode", d.to(dev), out, d.shape[0], degree)
+    torch.testing.assert_close(out.cpu(), ref, rtol=0, atol=4e-6)
+    out4 = torch.empty(d.shape[0], 16, device=dev)
+    capi.call("sh_encode", d.to(dev), out4, d.shape[0], 4)
+    assert torch.equal(out[:, :16], out4)
+    assert capi.lib().cdll.f2n_sh_encode(d.to(dev).data_ptr(), out.data_ptr(), 10, 9, None) == -3
+
+
 # --------------------------------------------------------------------------------- segments -----
 
 

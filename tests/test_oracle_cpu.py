@@ -146,6 +146,53 @@ def test_sh_basis_is_orthonormal():
     assert torch.allclose(y[1:4], torch.tensor([0.48 * c1, 0.64 * c1, -0.6 * c1]), atol=1e-6)
 
 
+def test_sh_bands_4_to_7_match_the_closed_forms_the_reference_documents():
+    """Degrees 5..8: the oracle evaluates the defining recurrences in double; the reference's
+    comments (src/sh_shader.cu:52-102) give each entry in closed form.  A dozen of them -- every
+    band's m = -l, 0, +l and some in between -- pin ordering, signs and normalisation; the Gram
+    matrix over the sphere pins the rest up to rotation within a band."""
+    g = torch.Generator().manual_seed(5)
+    d = torch.randn(257, 3, generator=g, dtype=torch.float64)
+    d = d / d.norm(dim=1, keepdim=True)
+    Y = K.sh_encode(d.float(), 8).double()
+    x, y, z = d[:, 0], d[:, 1], d[:, 2]
+    x2, y2, z2 = x * x, y * y, z * z
+    x4, y4, z4, x6, y6, z6 = x2 * x2, y2 * y2, z2 * z2, x2 ** 3, y2 ** 3, z2 ** 3
+    sp = math.sqrt(math.pi)
+    want = {
+        16: 3 * math.sqrt(35) * x * y * (x2 - y2) / (4 * sp),
+        20: 3 * (-30 * z2 + 35 * z4 + 3) / (16 * sp),
+        24: 3 * math.sqrt(35) * (-6 * x2 * y2 + x4 + y4) / (16 * sp),
+        25: 3 * math.sqrt(154) * y * (10 * x2 * y2 - 5 * x4 - y4) / (32 * sp),
+        27: -math.sqrt(770) * y * (3 * x2 - y2) * (9 * z2 - 1) / (32 * sp),
+        30: math.sqrt(11) * z * (-70 * z2 + 63 * z4 + 15) / (16 * sp),
+        35: 3 * math.sqrt(154) * x * (10 * x2 * y2 - x4 - 5 * y4) / (32 * sp),
+        36: math.sqrt(6006) * x * y * (-10 * x2 * y2 + 3 * x4 + 3 * y4) / (32 * sp),
+        42: math.sqrt(13) * (105 * z2 - 315 * z4 + 231 * z6 - 5) / (32 * sp),
+        45: -math.sqrt(2730) * x * z * (x2 - 3 * y2) * (11 * z2 - 3) / (32 * sp),
+        48: math.sqrt(6006) * (15 * x2 * y4 - 15 * x4 * y2 + x6 - y6) / (64 * sp),
+        49: 3 * math.sqrt(715) * y * (-21 * x2 * y4 + 35 * x4 * y2 - 7 * x6 + y6) / (64 * sp),
+        56: math.sqrt(15) * z * (315 * z2 - 693 * z4 + 429 * z6 - 35) / (32 * sp),
+        58: math.sqrt(70) * z * (x2 - y2) * (143 * z2 * (3 * z2 - 1) - 187 * z2 + 45) / (64 * sp),
+        63: 3 * math.sqrt(715) * x * (-35 * x2 * y4 + 21 * x4 * y2 - x6 + 7 * y6) / (64 * sp),
+    }
+    for idx, w in want.items():
+        assert (Y[:, idx] - w).abs().max() < 3e-6, idx
+    # degrees 5..8 are prefixes of one another, and degree 4 is the prefix the renderer uses
+    for deg in (4, 5, 6, 7):
+        assert torch.equal(K.sh_encode(d.float(), deg), K.sh_encode(d.float(), 8)[:, :deg * deg])
+    nt, npz = 64, 128
+    xs, wq = np.polynomial.legendre.leggauss(nt)
+    phi = (np.arange(npz) + 0.5) * 2 * np.pi / npz
+    ct, ph = np.meshgrid(xs, phi, indexing="ij")
+    st = np.sqrt(1 - ct ** 2)
+    dirs = np.stack([st * np.cos(ph), st * np.sin(ph), ct], -1).reshape(-1, 3)
+    w = (wq[:, None] * np.full((1, npz), 2 * np.pi / npz)).reshape(-1)
+    Yq = K.sh_encode(torch.tensor(dirs, dtype=torch.float32), 8).double().numpy()
+    gram = (Yq * w[:, None]).T @ Yq
+    assert np.abs(gram - np.eye(64)).max() < 5e-5
+
+
 def _seg_loop(val, idx, fn):
     return [fn(val[s:e]) for s, e in idx.tolist()]
 
