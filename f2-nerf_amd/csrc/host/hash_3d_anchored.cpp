@@ -166,7 +166,7 @@ std::pair<Tensor, Tensor> Hash3DAnchored::density_head() const
           mlp_->bias.detach().slice(0, 0, 1).contiguous()};
 }
 
-Tensor Hash3DAnchored::encode(const Tensor & points, int64_t samples_per_ray)
+Tensor Hash3DAnchored::encode(const Tensor & points, int64_t samples_per_ray, Tensor * contracted_out)
 {
   auto info = torch::make_intrusive<Hash3DAnchoredInfo>();
   info->hash3d_ = this;
@@ -174,10 +174,12 @@ Tensor Hash3DAnchored::encode(const Tensor & points, int64_t samples_per_ray)
 
   // scene contraction (reference .cpp:79-82: eight ATen launches) as one kernel each way
   Tensor x = ContractFn::apply(points)[0];
+  if (contracted_out) *contracted_out = x.detach();
   return torch::autograd::Hash3DAnchoredFunction::apply(x, feat_pool_, torch::IValue(info))[0];
 }
 
-Tensor Hash3DAnchored::encode_cached(const Tensor & points, const Tensor & enc_cm)
+Tensor Hash3DAnchored::encode_cached(
+  const Tensor & points, const Tensor & enc_cm, const Tensor & contracted)
 {
   TORCH_CHECK(
     enc_cm.dim() == 2 && enc_cm.is_contiguous() && enc_cm.size(1) == points.size(0) &&
@@ -186,7 +188,9 @@ Tensor Hash3DAnchored::encode_cached(const Tensor & points, const Tensor & enc_c
   auto info = torch::make_intrusive<Hash3DAnchoredInfo>();
   info->hash3d_ = this;
   info->precomputed_cm_ = enc_cm;
-  Tensor x = ContractFn::apply(points)[0];
+  const bool reuse = contracted.defined() && contracted.sizes() == points.sizes() &&
+                     !(torch::GradMode::is_enabled() && points.requires_grad());
+  Tensor x = reuse ? contracted : ContractFn::apply(points)[0];
   return torch::autograd::Hash3DAnchoredFunction::apply(x, feat_pool_, torch::IValue(info))[0];
 }
 

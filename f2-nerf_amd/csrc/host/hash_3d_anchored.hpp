@@ -42,12 +42,16 @@ public:
   // fused path feeds this straight into the fused per-sample network kernel.
   // samples_per_ray > 0 declares `points` a dense ray-major [n_rays, samples_per_ray] grid: the
   // forward then walks neighbouring rays per wavefront (f2n_hash_fwd_raytile), same results.
-  Tensor encode(const Tensor & points, int64_t samples_per_ray = 0);
+  // contracted_out, if given, receives the contracted points (to hand back to encode_cached).
+  Tensor encode(const Tensor & points, int64_t samples_per_ray = 0, Tensor * contracted_out = nullptr);
 
   // Same autograd node as encode(), but the forward result is supplied: `enc_cm` [L*F, n]
   // channel-major, the encoding of exactly these points computed earlier (the Renderer's first pass).
   // Only the backward (table gradient) runs a kernel.
-  Tensor encode_cached(const Tensor & points, const Tensor & enc_cm);
+  // `contracted`, if defined, is the contraction of exactly these points (from encode()); it is
+  // used as is when the points carry no gradient.
+  Tensor encode_cached(
+    const Tensor & points, const Tensor & enc_cm, const Tensor & contracted = Tensor());
 
   // Row 0 of mlp_ (weight [L*F], bias [1]) as contiguous device tensors: the density head the fused
   // ray march evaluates in-kernel.

@@ -176,7 +176,8 @@ class CompositeFn : public torch::autograd::Function<CompositeFn>
 {
 public:
   static variable_list forward(
-    AutogradContext * ctx, Tensor field_out, Tensor rgb, Tensor dt, Tensor t, Tensor idx, Tensor bg)
+    AutogradContext * ctx, Tensor field_out, Tensor rgb, Tensor dt, Tensor t, Tensor idx, Tensor bg,
+    bool tiled)
   {
     field_out = f2n::dev_f32(field_out, "composite field_out");
     rgb = f2n::dev_f32(rgb, "composite rgb");
@@ -189,7 +190,9 @@ public:
     const int n_rays = (int)idx.size(0);
     auto opt = field_out.options();
     Tensor colors = torch::empty({n_rays, 3}, opt), depths = torch::empty({n_rays}, opt);
-    Tensor weights = torch::zeros({n}, opt), last_trans = torch::empty({n_rays}, opt);
+    Tensor weights = tiled ? torch::empty({n}, opt) : torch::zeros({n}, opt);
+    Tensor last_trans = torch::empty({n_rays}, opt);
+    ctx->saved_data["tiled"] = tiled;
     f2n::check(
       f2n_composite_fwd(
         f2n::fptr(field_out), field_out.size(1), f2n::fptr(rgb), f2n::fptr(dt), f2n::fptr(t),
@@ -215,7 +218,9 @@ public:
                                                : torch::zeros({n_rays}, opt);
     Tensor d_weights =
       grad_output[2].defined() ? f2n::dev_f32(grad_output[2], "d_weights") : Tensor();
-    Tensor d_logit = torch::zeros({n}, opt), d_rgb = torch::zeros({n, 3}, opt);
+    const bool tiled = ctx->saved_data["tiled"].toBool();
+    Tensor d_logit = tiled ? torch::empty({n}, opt) : torch::zeros({n}, opt);
+    Tensor d_rgb = tiled ? torch::empty({n, 3}, opt) : torch::zeros({n, 3}, opt);
     f2n::check(
       f2n_composite_bwd(
         f2n::fptr(field_out), field_out.size(1), f2n::fptr(rgb), f2n::fptr(dt), f2n::fptr(t),
@@ -224,10 +229,10 @@ public:
         d_rgb.data_ptr<float>(), n_rays, 3.f, 1e-2f, f2n::current_stream(field_out)),
       "f2n_composite_bwd");
     if (field_out.size(1) == 1)  // the fused path hands over the logit column alone
-      return {d_logit.unsqueeze(1), d_rgb, Tensor(), Tensor(), Tensor(), Tensor()};
+      return {d_logit.unsqueeze(1), d_rgb, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
     Tensor d_field = torch::zeros_like(field_out);
     d_field.select(1, 0).copy_(d_logit);
-    return {d_field, d_rgb, Tensor(), Tensor(), Tensor(), Tensor()};
+    return {d_field, d_rgb, Tensor(), Tensor(), Tensor(), Tensor(), Tensor()};
   }
 };
 
@@ -438,9 +443,9 @@ f2n::ShadeOut f2n::shade(
 
 f2n::CompositeOut f2n::composite(
   const Tensor & field_out, const Tensor & rgb, const Tensor & dt, const Tensor & t,
-  const Tensor & idx_start_end, const Tensor & bg_color)
+  const Tensor & idx_start_end, const Tensor & bg_color, bool bounds_tile_samples)
 {
-  auto out = CompositeFn::apply(field_out, rgb, dt, t, idx_start_end, bg_color);
+  auto out = CompositeFn::apply(field_out, rgb, dt, t, idx_start_end, bg_color, bounds_tile_samples);
   return {out[0], out[1], out[2]};
 }
 

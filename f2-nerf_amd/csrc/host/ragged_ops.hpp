@@ -47,9 +47,11 @@ struct CompositeOut
 // Fused statement of reference src/renderer.cpp:93,107-118 (density activation, alpha, exclusive
 // optical-depth scan, weights, colour/depth sums, background blend), differentiable in `field_out`
 // (column 0 = density logit; gradient returned dense, zero in the other columns) and `rgb`.
+// `bounds_tile_samples`: the caller guarantees that the rays' [start, end) ranges tile [0, n) (the
+// Renderer's own bounds do): per-sample outputs are then written whole and need no zero fill.
 CompositeOut composite(
   const Tensor & field_out, const Tensor & rgb, const Tensor & dt, const Tensor & t,
-  const Tensor & idx_start_end, const Tensor & bg_color);
+  const Tensor & idx_start_end, const Tensor & bg_color, bool bounds_tile_samples = false);
 
 
 struct ShadeOut

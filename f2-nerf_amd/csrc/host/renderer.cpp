@@ -83,11 +83,12 @@ RenderResult Renderer::render_fused(
     SampleResultFlex all = pts_sampler_->get_samples(rays_o, rays_d, noise);
     const int64_t n_all = all.pts.size(0);
     SampleResultFlex kept;
-    Tensor enc_kept_cm;
+    Tensor enc_kept_cm, contracted_kept;
     {
       torch::NoGradGuard no_grad;
       // all.pts is the dense [n_rays, S] grid of the sampler: ray-tile mapping of the encode
-      Tensor enc_all_cm = field.encode(all.pts, S).t();  // [C, n_all] contiguous storage
+      Tensor contracted_all;
+      Tensor enc_all_cm = field.encode(all.pts, S, &contracted_all).t();  // [C, n_all] contiguous storage
       TORCH_CHECK(enc_all_cm.is_contiguous(), "encode() must return channel-major storage");
       auto head = field.density_head();
       Tensor counts = torch::empty({n_rays}, iopt);
@@ -117,6 +118,7 @@ RenderResult Renderer::render_fused(
         kept.dt = all.dt;
         kept.t = all.t;
         enc_kept_cm = enc_all_cm;
+        contracted_kept = contracted_all;  // ... and so are their contracted positions
       } else {
         kept.pts = torch::empty({n_kept, 3}, fopt);
         kept.dirs = torch::empty({n_kept, 3}, fopt);
@@ -137,7 +139,7 @@ RenderResult Renderer::render_fused(
           "f2n_compact_rows_cm");
       }
     }
-    return shade_and_composite(kept, emb_idx, mode, bg_color, enc_kept_cm);
+    return shade_and_composite(kept, emb_idx, mode, bg_color, enc_kept_cm, contracted_kept);
   }
 
   SampleResultFlex kept;
@@ -187,13 +189,13 @@ RenderResult Renderer::render_fused(
 // Second pass on the survivors (renderer.cpp:92-118).
 RenderResult Renderer::shade_and_composite(
   const SampleResultFlex & kept, const Tensor & emb_idx, RunningMode mode, const Tensor & bg_color,
-  const Tensor & enc_cm)
+  const Tensor & enc_cm, const Tensor & contracted)
 {
   const int64_t n_kept = kept.pts.size(0);
   const int64_t C = scene_field_->options_.n_levels * scene_field_->options_.n_channels;
   if (options_.fused_shade && f2n::shade_supported(C) && scene_field_->options_.mlp_out_dim == 16) {
     // hash encode -> one kernel for field head + embedding + SH + colour MLP -> composite
-    Tensor enc = enc_cm.defined() ? scene_field_->encode_cached(kept.pts, enc_cm)
+    Tensor enc = enc_cm.defined() ? scene_field_->encode_cached(kept.pts, enc_cm, contracted)
                                   : scene_field_->encode(kept.pts);
     Tensor sample_img;
     if (mode == RunningMode::TRAIN)
@@ -202,8 +204,9 @@ RenderResult Renderer::shade_and_composite(
     f2n::ShadeOut sh = f2n::shade(
       enc, kept.dirs, sample_img, scene_field_->mlp_->weight, scene_field_->mlp_->bias, mlp[0],
       mlp[1], mlp[2], mlp[3], mode == RunningMode::TRAIN ? app_emb_ : Tensor());
+    // (kept.pts_idx_bounds comes from f2n_bounds_from_counts / the sampler: the ranges tile [0, n))
     f2n::CompositeOut out = f2n::composite(
-      sh.logit.unsqueeze(1), sh.rgb, kept.dt, kept.t, kept.pts_idx_bounds, bg_color);
+      sh.logit.unsqueeze(1), sh.rgb, kept.dt, kept.t, kept.pts_idx_bounds, bg_color, true);
     return {out.colors, out.depths, out.weights, kept.pts_idx_bounds};
   }
   Tensor scene_feat = scene_field_->query(kept.pts);  // [n, 16]: col 0 density logit, 1.. shading

@@ -90,7 +90,7 @@ private:
     const Tensor & noise, const Tensor & bg_color);
   RenderResult shade_and_composite(
     const SampleResultFlex & kept, const Tensor & emb_idx, RunningMode mode,
-    const Tensor & bg_color, const Tensor & enc_cm = Tensor());
+    const Tensor & bg_color, const Tensor & enc_cm = Tensor(), const Tensor & contracted = Tensor());
 };
 
 namespace f2n
