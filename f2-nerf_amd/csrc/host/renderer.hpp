@@ -22,6 +22,27 @@
 #include "points_sampler.hpp"
 #include "sh_shader.hpp"
 
+namespace f2n
+{
+// One int32 read back from the device without stalling the enqueue side: request() starts the copy
+// into pinned memory behind everything already on the stream, wait() blocks on just that copy.
+class HostCount
+{
+public:
+  HostCount() = default;
+  HostCount(const HostCount &) = delete;
+  HostCount & operator=(const HostCount &) = delete;
+  ~HostCount();
+  void request(const torch::Tensor & device_int32, void * stream);
+  int64_t wait();
+
+private:
+  int32_t * pinned_ = nullptr;
+  void * event_ = nullptr;
+  bool pending_ = false;
+};
+}  // namespace f2n
+
 struct RenderResult
 {
   using Tensor = torch::Tensor;
@@ -44,6 +65,10 @@ struct RendererOptions
   // instead of twice when little terminates; march: stop rays in-kernel, re-encode survivors.
   int dense_first_pass = -1;
   float early_stop_trans = 1e-4f;  // renderer.cpp:68
+  // Dense first pass: when the previous chunk kept every sample, enqueue the shading pass for "kept
+  // everything" before the host reads this chunk's survivor count (see render_fused); results are
+  // identical either way.
+  bool speculate_dense = true;
   bool check_finite = false;       // the reference's CHECK(isfinite(colors.mean())) host sync
 };
 
@@ -80,6 +105,7 @@ public:
 
   int64_t last_n_samples_ = 0;  // survivors of the most recent render() (bench bookkeeping)
   float last_kept_fraction_ = 0.f;
+  f2n::HostCount survivors_;
 
 private:
   RenderResult render_fused(

@@ -130,6 +130,53 @@ def test_train_step_matches_oracle(host, dev, L, F, log2_T, S, step, bias0):
         assert grads["scene_field.bias_pool"] is None or float(grads["scene_field.bias_pool"].abs().sum()) == 0
 
 
+def test_dense_pass_guess_changes_nothing(host, dev):
+    """The dense first pass enqueues the "nothing terminated" shading before the host has read the
+    survivor count (renderer.cpp, HostCount).  Right guess, wrong guess, no guess: same results."""
+    L, F, log2_T, S, step = 4, 2, 14, 64, 4.0 / 64
+    oracle, hr, o, d, noise, bg, gt, emb = _setup(host, L, F, log2_T, S, step, 96, -3.0, 31)
+    to = lambda x: x.to(dev)
+    hr.set_fused(True)
+    hr.set_fused_shade(True)
+    hr.set_dense_first_pass(1)
+    params = hr.named_parameters()
+
+    def step_once(speculate):
+        hr.set_speculate_dense(speculate)
+        hr.zero_grad()
+        out = hr.render(to(o), to(d), to(emb), "train", to(noise), to(bg))
+        hr.zero_grad()
+        hr.train_step(to(o), to(d), to(emb), to(gt), 1e-2, to(noise), to(bg), True)
+        grads = {k: (None if v is None else v.clone()) for k, v in hr.grads().items()}
+        return [t.detach().clone() for t in out], grads
+
+    def same(a, b):
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y)
+        for k in a[1]:   # parameter gradients are sums by float atomics: equal up to their order
+            if a[1][k] is not None:
+                scale = float(b[1][k].abs().max())
+                torch.testing.assert_close(a[1][k], b[1][k], rtol=1e-4, atol=1e-5 * scale + 1e-30)
+
+    # thin medium: every sample survives, so after one call the guess is made and is right
+    ref_dense = step_once(False)
+    assert hr.last_kept_fraction == 1.0
+    got = step_once(True)
+    assert hr.last_kept_fraction == 1.0
+    same(got, ref_dense)
+    # now the medium turns opaque between two calls: the guess (made because the last call kept
+    # everything) is wrong and must be thrown away
+    with torch.no_grad():
+        params["scene_field.mlp.bias"][0] = 8.0
+    hr.set_speculate_dense(True)
+    out_wrong = hr.render(to(o), to(d), to(emb), "train", to(noise), to(bg))
+    assert hr.last_kept_fraction < 0.9
+    wrong = ([t.detach().clone() for t in out_wrong], {})
+    ref_term = step_once(False)
+    same(wrong, (ref_term[0], {}))
+    same(step_once(True), ref_term)
+
+
 def test_config_c3_view_chunk_properties(host, dev):
     """BASELINE config C3 at its own size: one 1920 x 1080 free-trajectory view, 192 samples per ray.
     The oracle needs minutes at this size, so the full-width chunk is checked through properties:
