@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--zero-rays", type=float, default=0.0, help="fraction of rays whose gradient is zero")
     ap.add_argument("--grad-scale", type=float, default=1e-3, help="std of the synthetic gradient")
     ap.add_argument("--levels", type=int, default=0, help="override L")
+    ap.add_argument("--other", action="append", default=[], metavar="NAME",
+                    help="also time tools/ab/libf2nerf_hip_NAME.so (an experimental build)")
     args = ap.parse_args()
     capi = importlib.import_module("f2-nerf_amd").capi
     dev = torch.device("cuda:0")
@@ -99,6 +101,8 @@ def main():
     if os.path.exists(old_path):
         old = ctypes.CDLL(old_path)
         libs.append(("round 1", old))
+    for name in args.other:
+        libs.append((name, ctypes.CDLL(os.path.join(ROOT, "tools", "ab", "libf2nerf_hip_%s.so" % name))))
     print("config %s: n=%d (%d rays x %d) L=%d F=%d T=2^%d, points=%s" % (args.config, n, n_rays, S, L, F, log2_T, args.points))
     stream = torch.cuda.current_stream().cuda_stream
     for name, lib in libs:
