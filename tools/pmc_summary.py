@@ -44,7 +44,7 @@ def main(argv):
     dirs = opts.dirs
     acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for d in dirs:
-        for f in glob.glob(d + "/*/*counter_collection.csv"):
+        for f in glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"):
             for row in csv.DictReader(open(f)):
                 k = short(row["Kernel_Name"])
                 if not k:
