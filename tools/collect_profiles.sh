@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects what profiles/ holds for one round on a GPU box (run through gpurun from the repo root):
-#   tools/collect_profiles.sh c2|c4c5|misc OUTDIR
+#   tools/collect_profiles.sh c2|c4c5|misc|lines OUTDIR
 # bench JSON lines, rocprofv3 kernel-trace stats and the two PMC passes (FETCH_SIZE, WRITE_SIZE in
 # separate runs, kernel-trace only next to them), each step under its own timeout.
 set -eo pipefail
@@ -45,6 +45,10 @@ case $what in
     prof c5_stats stats -- --workload c5 --steps 2 --warmup 1 --no-cpu-baseline
     prof pmc_fetch_c5 pmc FETCH_SIZE -- --workload c5 --steps 1 --warmup 1 --no-cpu-baseline
     prof pmc_write_c5 pmc WRITE_SIZE -- --workload c5 --steps 1 --warmup 1 --no-cpu-baseline
+    ;;
+  lines)  # the bench lines again, once the PMC summaries of this build are in profiles/
+    bench bench_c2 --steps 20 --warmup 5
+    bench bench_c5 --workload c5 --steps 3 --warmup 1
     ;;
   misc)
     bench bench_c2_term --steps 10 --warmup 3 --no-cpu-baseline --regime terminating
