@@ -127,7 +127,8 @@ int f2n_contract_bwd(const float * pts, const float * dx, float * dpts, int64_t 
 
 /* ------------------------------------------------------------------ SH encode (row A6) -------- */
 
-/* SHKernel<<<ceil(n/512), 512>>> -- src/sh_shader.cu:11-115.  dirs [n,3] -> out [n, degree^2]. */
+/* SHKernel<<<ceil(n/512), 512>>> -- src/sh_shader.cu:11-115.  dirs [n,3] -> out [n, degree^2],
+ * degree 1..8 (F2N_E_UNSUPPORTED above); out 16-byte aligned. */
 int f2n_sh_encode(const float * dirs, float * out, int64_t n, int degree, void * stream);
 
 /* ------------------------------------------------------------------ ragged per-ray ops (A7) --- */
