@@ -56,6 +56,9 @@ constexpr int kMaxLog2Sub = 6;
 // Record of F channels: word 0 = row inside the bucket, then the F halves packed two per word.
 // F <= 2: array of {row, value} pairs (8 bytes).  F >= 4: structure of arrays inside each region
 // (all rows, then all value groups of 8 / 16 bytes) so both parts move as full-width vector accesses.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
 template <int F>
 struct Rec
 {
@@ -359,12 +362,15 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
         asm volatile("" : "+v"(c0));  // keep the f32 rounding before the f16 one (see round_f16)
         val[0] = (uint32_t)__half_as_ushort(__float2half_rn(c0));
       } else {
+        // two channels at a time: v_pk_mul_f32 + v_cvt_pk_f16_f32 (gfx950: two round-to-nearest-even
+        // conversions and the pack in one instruction) instead of two multiplies, two conversions, a
+        // shift and an or -- a third of this kernel's vector instructions were this expression
 #pragma unroll
         for (int k = 0; k < F; k += 2) {
-          float c0 = gk[k] * w[d], c1 = gk[k + 1] * w[d];
-          asm volatile("" : "+v"(c0), "+v"(c1));
-          val[k / 2] = (uint32_t)__half_as_ushort(__float2half_rn(c0)) |
-                       ((uint32_t)__half_as_ushort(__float2half_rn(c1)) << 16);
+          f32x2 c = {gk[k], gk[k + 1]};
+          c = c * w[d];
+          asm volatile("" : "+v"(c));  // keep the f32 rounding before the f16 one (see round_f16)
+          val[k / 2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(c, f16x2));
         }
       }
     };
@@ -373,7 +379,8 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       const uint32_t bucket = r >> a.bshift;
       const uint32_t slot = atomicAdd(&qcount[bucket], 1u);
       if (slot < (uint32_t)cap)
-        store_record<F>(queue + (size_t)bucket * cap * KW, cap, slot, r & bmask, val);
+        // (bucket < 64, cap * KW <= 32768: a 24-bit multiply is full rate, v_mul_lo_u32 a quarter)
+        store_record<F>(queue + __umul24(bucket, (uint32_t)(cap * KW)), cap, slot, r & bmask, val);
       else
         apply_record_atomic<F>(gbase, r, val, a.inv_scale);
     };
@@ -383,6 +390,49 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       uint32_t * region0 =
         ws_records + ((size_t)l * n_tiles_g + tile_g) * a.n_buckets * (size_t)a.qcap * KW;
       if constexpr (!Rec<F>::kSoA) {
+        if (a.n_buckets == 4 * kWaves) {
+          // 64 buckets, four per wave (w, w+16, w+32, w+48): their queues are copied as ONE flat list
+          // -- lane f takes the f-th record of the four queues together -- so that the sparse queues
+          // of a tile whose contributions mostly underflow (a dozen records each) cost one 64-lane
+          // pass and ~50 instructions instead of four masked passes and ~180.  This kernel is bound
+          // by instruction issue and the flush was its largest piece (bench workload: the whole
+          // backward 2.27 -> 2.11 ms; full queues, 512 records per wave, lose 2-5 %).
+          uint32_t c[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            c[u] = (uint32_t)__builtin_amdgcn_readfirstlane(
+              (int)min(qcount[wave + kWaves * u], (uint32_t)cap));
+          const uint32_t p1 = c[0], p2 = p1 + c[1], p3 = p2 + c[2], total = p3 + c[3];
+          const uint2 * src = reinterpret_cast<const uint2 *>(queue) + (uint32_t)wave * (uint32_t)cap;
+          uint2 * dst = reinterpret_cast<uint2 *>(region0) + (uint32_t)wave * (uint32_t)a.qcap;
+          const uint32_t su = (uint32_t)(kWaves * cap), du = (uint32_t)(kWaves * a.qcap);
+          auto locate = [&](uint32_t f, uint32_t & from, uint32_t & to) {
+            const bool g1 = f >= p1, g2 = f >= p2, g3 = f >= p3;
+            const uint32_t u = (g1 ? 1u : 0u) + (g2 ? 1u : 0u) + (g3 ? 1u : 0u);
+            const uint32_t i = f - (g1 ? c[0] : 0u) - (g2 ? c[1] : 0u) - (g3 ? c[2] : 0u);
+            from = __umul24(u, su) + i;
+            to = __umul24(u, du) + i;
+          };
+          uint32_t f = (uint32_t)lane;
+          for (; f + 64u < total; f += 128u) {  // two passes at a time: both loads before the stores
+            uint32_t from0, to0, from1, to1;
+            locate(f, from0, to0);
+            locate(f + 64u, from1, to1);
+            const uint2 v0 = src[from0], v1 = src[from1];
+            dst[to0] = v0;
+            dst[to1] = v1;
+          }
+          if (f < total) {
+            uint32_t from0, to0;
+            locate(f, from0, to0);
+            dst[to0] = src[from0];
+          }
+          if (lane < 4) {
+            const uint32_t mine = lane == 0 ? c[0] : lane == 1 ? c[1] : lane == 2 ? c[2] : c[3];
+            ws_counts[((size_t)l * a.n_buckets + (wave + kWaves * lane)) * n_tiles_g + tile_g] = mine;
+          }
+          return;
+        }
         // the LDS reads of up to four buckets are issued before the first store
         for (int b0 = wave; b0 < a.n_buckets; b0 += 4 * kWaves) {
           uint2 v[4][4];
@@ -414,9 +464,12 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
             queue + (size_t)b * cap * KW, cap, region0 + (size_t)b * a.qcap * KW, a.qcap, 0u, cnt, lane);
         }
       }
-      if ((int)threadIdx.x < a.n_buckets)
-        ws_counts[((size_t)l * a.n_buckets + threadIdx.x) * n_tiles_g + tile_g] =
-          min(qcount[threadIdx.x], (uint32_t)cap);
+      // every wave records the counts of the buckets it copied (w, w+16, ...: at most four)
+      if (lane < kMaxBuckets / kWaves) {
+        const int b = wave + kWaves * lane;
+        if (b < a.n_buckets)
+          ws_counts[((size_t)l * a.n_buckets + b) * n_tiles_g + tile_g] = min(qcount[b], (uint32_t)cap);
+      }
     };
 
     __syncthreads();  // the previous level's flush has read the queues and counters
