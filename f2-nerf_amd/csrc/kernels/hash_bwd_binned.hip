@@ -306,10 +306,14 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
     __syncthreads();
     if (threadIdx.x == 0) {
       const uint32_t breaks = comb_state[3] - comb_state[2] + (uint32_t)kWaves;  // runs in the tile
-      const uint32_t run_q8 = (uint32_t)(((uint64_t)(comb_state[3] + kWaves) << 8) / breaks);
-      comb_state[4] = run_q8;
-      comb_state[0] =
-        (run_q8 >= (uint32_t)kCombineMinRunQ8 || comb_state[1] >= (uint32_t)kCombineDenseTile) ? 1u : 0u;
+      // mean run (x256) = 256 (lanes + waves) / breaks; the comparison needs no division, and the
+      // quotient itself only matters to a tile that combines (a 64-bit division is ~150 dependent
+      // instructions of this one thread while 1023 wait)
+      const uint64_t lanes_q8 = (uint64_t)(comb_state[3] + kWaves) << 8;
+      const bool on = lanes_q8 >= (uint64_t)kCombineMinRunQ8 * breaks ||
+                      comb_state[1] >= (uint32_t)kCombineDenseTile;
+      comb_state[0] = on ? 1u : 0u;
+      if (on) comb_state[4] = (uint32_t)(lanes_q8 / breaks);
       if (a.stats) {
         atomicAdd(a.stats + 3, comb_state[1]);
         atomicAdd(a.stats + 7, 1u);
