@@ -129,6 +129,34 @@ RenderResult Renderer::render_fused(
       // all.pts is the dense [n_rays, S] grid of the sampler: ray-tile mapping of the encode
       enc_all_cm = field.encode(all.pts, S, &contracted_all).t();  // [C, n_all] contiguous storage
       TORCH_CHECK(enc_all_cm.is_contiguous(), "encode() must return channel-major storage");
+    }
+    // The number of survivors sizes everything downstream, so the host has to read it: one blocking
+    // read per chunk.  When the previous chunk kept every sample the next one most likely does too
+    // (no density yet, or validation of empty space), so that case is tried first and for free: the
+    // shading pass is run over ALL samples (fresh buffers, nothing observable), the density logits
+    // it produces anyway are summed per ray (f2n_density_margin: 67 MB instead of the 1 GB encoding
+    // the exact scan reads) and a flag says whether some ray comes within a factor e^0.5 of the
+    // early-stop threshold.  Flag clear = the exact scan would keep everything too (its logits
+    // differ from these in the last bits only): the guess IS the result, and neither the scan
+    // (0.22 ms per 8.4 M samples) nor an idle GPU across the read (the flag travels while
+    // compositing runs) was paid.  Flag set = drop the guess, run the exact scan, compact.
+    //   Small chunks (the 512-ray training batch) keep the exact scan instead -- there it costs
+    // 20 us, less than the GPU would idle while the host waits for a flag that only exists after
+    // the shading pass -- and hide ITS read-back behind the same guess (further down).
+    const bool may_guess = options_.speculate_dense && last_kept_fraction_ >= 1.f && n_all > 0;
+    const int64_t kMarginMinSamples = options_.margin_min_samples;
+    if (may_guess && n_all >= kMarginMinSamples) {
+      Tensor near_threshold = torch::zeros({1}, iopt);
+      RenderResult guess = shade_and_composite(
+        all, emb_idx, mode, bg_color, enc_all_cm, contracted_all, &near_threshold, S);
+      if (survivors_.wait() == 0) {
+        last_n_samples_ = n_all;
+        last_kept_fraction_ = 1.f;
+        return guess;
+      }
+    }
+    {
+      torch::NoGradGuard no_grad;
       auto head = field.density_head();
       Tensor counts = torch::empty({n_rays}, iopt);
       {
@@ -147,17 +175,11 @@ RenderResult Renderer::render_fused(
           total.data_ptr<int32_t>(), n_rays, stream),
         "f2n_bounds_from_counts");
     }
-    // The number of survivors sizes everything downstream, so the host has to read it: one
-    // blocking read per chunk, during which the GPU would idle (wake-up + the launches that follow:
-    // ~25 us, 3 % of a 512-ray training iteration).  When the previous chunk kept every sample the
-    // next one most likely does too (no density yet, or validation of empty space): the shading pass
-    // for "nothing terminated" is enqueued BEFORE the host waits -- fresh buffers only, nothing
-    // observable -- and kept if the count agrees; otherwise it is dropped and the chunk takes the
-    // compaction path as before (the price of a wrong guess: one shading pass over n_all samples).
     survivors_.request(total, stream);
     RenderResult guess;
     bool guessed = false;
-    if (options_.speculate_dense && last_kept_fraction_ >= 1.f && n_all > 0) {
+    if (may_guess && n_all < kMarginMinSamples) {
+      // enqueued BEFORE the host waits for the count: the GPU does not idle across the read
       guess = shade_and_composite(all, emb_idx, mode, bg_color, enc_all_cm, contracted_all);
       guessed = true;
     }
@@ -246,7 +268,7 @@ RenderResult Renderer::render_fused(
 // Second pass on the survivors (renderer.cpp:92-118).
 RenderResult Renderer::shade_and_composite(
   const SampleResultFlex & kept, const Tensor & emb_idx, RunningMode mode, const Tensor & bg_color,
-  const Tensor & enc_cm, const Tensor & contracted)
+  const Tensor & enc_cm, const Tensor & contracted, Tensor * near_threshold, int64_t grid_samples)
 {
   const int64_t n_kept = kept.pts.size(0);
   const int64_t C = scene_field_->options_.n_levels * scene_field_->options_.n_channels;
@@ -261,6 +283,18 @@ RenderResult Renderer::shade_and_composite(
     f2n::ShadeOut sh = f2n::shade(
       enc, kept.dirs, sample_img, scene_field_->mlp_->weight, scene_field_->mlp_->bias, mlp[0],
       mlp[1], mlp[2], mlp[3], mode == RunningMode::TRAIN ? app_emb_ : Tensor());
+    if (near_threshold) {
+      // `kept` is the sampler's dense [n_rays, grid_samples] grid: see render_fused
+      torch::NoGradGuard no_grad;
+      void * stream = f2n::current_stream(sh.logit);
+      const float limit = -std::log(options_.early_stop_trans) - 0.5f;
+      f2n::check(
+        f2n_density_margin(
+          sh.logit.data_ptr<float>(), kept.dt.data_ptr<float>(), near_threshold->data_ptr<int32_t>(),
+          (int)(n_kept / grid_samples), (int)grid_samples, 3.f, limit, stream),
+        "f2n_density_margin");
+      survivors_.request(*near_threshold, stream);
+    }
     // (kept.pts_idx_bounds comes from f2n_bounds_from_counts / the sampler: the ranges tile [0, n))
     f2n::CompositeOut out = f2n::composite(
       sh.logit.unsqueeze(1), sh.rgb, kept.dt, kept.t, kept.pts_idx_bounds, bg_color, true);

@@ -65,10 +65,13 @@ struct RendererOptions
   // instead of twice when little terminates; march: stop rays in-kernel, re-encode survivors.
   int dense_first_pass = -1;
   float early_stop_trans = 1e-4f;  // renderer.cpp:68
-  // Dense first pass: when the previous chunk kept every sample, enqueue the shading pass for "kept
-  // everything" before the host reads this chunk's survivor count (see render_fused); results are
+  // Dense first pass: when the previous chunk kept every sample, shade all samples first and accept
+  // that as the result if no ray comes near the early-stop threshold (see render_fused); results are
   // identical either way.
   bool speculate_dense = true;
+  // ... chunks of at least this many samples accept the guess on the density-margin flag (no exact
+  // scan at all), smaller ones run the scan and only hide its read-back behind the guess
+  int64_t margin_min_samples = 2 << 20;
   bool check_finite = false;       // the reference's CHECK(isfinite(colors.mean())) host sync
 };
 
@@ -116,7 +119,8 @@ private:
     const Tensor & noise, const Tensor & bg_color);
   RenderResult shade_and_composite(
     const SampleResultFlex & kept, const Tensor & emb_idx, RunningMode mode,
-    const Tensor & bg_color, const Tensor & enc_cm = Tensor(), const Tensor & contracted = Tensor());
+    const Tensor & bg_color, const Tensor & enc_cm = Tensor(), const Tensor & contracted = Tensor(),
+    Tensor * near_threshold = nullptr, int64_t grid_samples = 0);
 };
 
 namespace f2n

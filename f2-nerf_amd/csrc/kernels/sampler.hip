@@ -249,6 +249,26 @@ __global__ __launch_bounds__(F2N_BLOCK) void density_scan_kernel(
   if (lane == 0) kept[r] = n_kept;
 }
 
+// ---- f2n_density_margin -------------------------------------------------------------------------
+// Does every ray of a dense [n_rays, S] grid keep all its samples with room to spare?  One wavefront
+// per ray sums the optical depth of its S density logits; a ray whose total reaches `depth_limit`
+// (or is not a number) sets flag[0].  The caller chooses depth_limit = -ln(threshold) - margin, so a
+// clear flag means the exact early-stop scan (f2n_density_scan, whose FMA order differs in the last
+// bits) would keep everything too.
+__global__ __launch_bounds__(F2N_BLOCK) void density_margin_kernel(
+  const float * __restrict__ logit, const float * __restrict__ dt, int32_t * __restrict__ flag,
+  int n_rays, int S, float density_shift, float depth_limit)
+{
+  const int r = ray_of_wave();
+  if (r >= n_rays) return;
+  const int lane = lane_id();
+  const int64_t base = (int64_t)r * S;
+  float sum = 0.f;
+  for (int k = lane; k < S; k += F2N_WAVE) sum += expf(logit[base + k] - density_shift) * dt[base + k];
+  sum = wave_sum(sum);
+  if (lane == 0 && !(sum < depth_limit)) atomicOr(flag, 1);
+}
+
 // ---- f2n_compact_rows_cm ------------------------------------------------------------------------
 // Channel-major compaction of per-ray prefixes: dst[c, new_start_r + k] = src[c, r*S + k], k < cnt_r.
 __global__ __launch_bounds__(F2N_BLOCK) void compact_rows_cm_kernel(
@@ -414,6 +434,19 @@ extern "C" int f2n_density_scan(
     default: F2N_SCAN(128); break;
   }
 #undef F2N_SCAN
+  return f2n_launch_status();
+}
+
+extern "C" int f2n_density_margin(
+  const float * logit, const float * dt, int32_t * flag, int n_rays, int S, float density_shift,
+  float depth_limit, void * stream)
+{
+  if (n_rays < 0 || S < 1) return F2N_E_INVALID_ARG;
+  if (n_rays == 0) return F2N_OK;
+  if (!logit || !dt || !flag) return F2N_E_INVALID_ARG;
+  hipLaunchKernelGGL(
+    density_margin_kernel, dim3(f2n_div_up(n_rays, F2N_WAVES_PER_BLOCK)), dim3(F2N_BLOCK), 0,
+    (hipStream_t)stream, logit, dt, flag, n_rays, S, density_shift, depth_limit);
   return f2n_launch_status();
 }
 

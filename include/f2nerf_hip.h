@@ -216,6 +216,16 @@ int f2n_density_scan(
   const float * enc_cm, int C, const float * dt, const float * w0, const float * b0, int32_t * kept,
   int n_rays, int S, float t_thresh, float density_shift, void * stream);
 
+/* A cheap sufficient test for "f2n_density_scan would keep every sample of every ray": logit
+ * [n_rays*S] are density logits of the dense grid (any evaluation of the field head, e.g. the fused
+ * per-sample network's), dt as above.  flag[0] (int32, zeroed by the caller) is set when some ray's
+ * total optical depth sum_k exp(logit_k - density_shift) dt_k is not below depth_limit; choose
+ * depth_limit = -ln(t_thresh) - margin with a margin far above the rounding differences between two
+ * evaluations of the logit (the host uses 0.5).  Part of the same block src/renderer.cpp:61-68. */
+int f2n_density_margin(
+  const float * logit, const float * dt, int32_t * flag, int n_rays, int S, float density_shift,
+  float depth_limit, void * stream);
+
 /* Channel-major companion of the four index() gathers at src/renderer.cpp:71-74 for [C, n] tensors:
  * dst[c, bounds[r].start + k] = src[c, r*S + k] for k < bounds[r].end - bounds[r].start. */
 int f2n_compact_rows_cm(

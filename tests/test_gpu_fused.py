@@ -183,3 +183,29 @@ def test_train_loss_matches_aten_formula(host, dev, n_rays, weight):
     torch.testing.assert_close(var.grad, v2.grad, rtol=1e-5, atol=1e-9)
     again = host.train_loss(colors.detach(), gt, var.detach(), weight)
     assert torch.equal(again, stats.detach())   # deterministic sums
+
+
+def test_density_margin_flag(capi, dev):
+    """f2n_density_margin: flag set iff some ray's optical depth reaches the limit (or is NaN); the
+    exact early-stop scan keeps every sample whenever the flag is clear (that is what the Renderer
+    relies on when it accepts the all-samples shading pass without running the scan)."""
+    g = torch.Generator().manual_seed(11)
+    n_rays, S, thresh = 300, 192, 1e-4
+    limit = -torch.log(torch.tensor(thresh)).item() - 0.5
+    dt = (torch.rand(n_rays, S, generator=g) * 0.04).reshape(-1)
+    for scale, poison in ((0.0, None), (1.0, None), (3.0, None), (0.0, 77)):
+        logit = (torch.randn(n_rays, S, generator=g) * 1.5 + scale).reshape(-1)
+        if poison is not None:
+            logit[poison * S + 5] = float("nan")
+        depth = (torch.exp(logit.double() - 3.0) * dt.double()).reshape(n_rays, S).sum(1)
+        want = bool((~(depth < limit)).any())
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        capi.call("density_margin", logit.to(dev), dt.to(dev), flag, n_rays, S, 3.0, float(limit))
+        assert bool(flag.item()) == want, (scale, poison)
+        if not want:
+            # sufficiency: exclusive prefix sums never reach -ln(thresh) either
+            sec = torch.exp(logit - 3.0) * dt
+            bounds = torch.arange(0, n_rays + 1, dtype=torch.int32) * S
+            idx = torch.stack([bounds[:-1], bounds[1:]], 1).contiguous()
+            acc = K.seg_scan_fwd(sec, idx, 0)
+            assert bool((torch.exp(-acc) > thresh).all())

@@ -130,15 +130,19 @@ def test_train_step_matches_oracle(host, dev, L, F, log2_T, S, step, bias0):
         assert grads["scene_field.bias_pool"] is None or float(grads["scene_field.bias_pool"].abs().sum()) == 0
 
 
-def test_dense_pass_guess_changes_nothing(host, dev):
-    """The dense first pass enqueues the "nothing terminated" shading before the host has read the
-    survivor count (renderer.cpp, HostCount).  Right guess, wrong guess, no guess: same results."""
+@pytest.mark.parametrize("margin_path", [False, True])
+def test_dense_pass_guess_changes_nothing(host, dev, margin_path):
+    """The dense first pass shades all samples on the guess that nothing terminates -- small chunks
+    before the host has read the exact survivor count, large ones (margin_path) instead of the exact
+    scan, accepted on the density-margin flag (renderer.cpp).  Right guess, wrong guess, no guess:
+    same results."""
     L, F, log2_T, S, step = 4, 2, 14, 64, 4.0 / 64
     oracle, hr, o, d, noise, bg, gt, emb = _setup(host, L, F, log2_T, S, step, 96, -3.0, 31)
     to = lambda x: x.to(dev)
     hr.set_fused(True)
     hr.set_fused_shade(True)
     hr.set_dense_first_pass(1)
+    hr.set_margin_min_samples(0 if margin_path else 1 << 40)
     params = hr.named_parameters()
 
     def step_once(speculate):
