@@ -130,6 +130,32 @@ def test_train_step_matches_oracle(host, dev, L, F, log2_T, S, step, bias0):
         assert grads["scene_field.bias_pool"] is None or float(grads["scene_field.bias_pool"].abs().sum()) == 0
 
 
+def test_render_edge_cases(host, dev):
+    """No rays at all (reference src/renderer.cpp:46-50: background, zero depth, weights filled with
+    512); one ray; a medium so dense that every ray stops after its first sample -- each against the
+    oracle, on the march and on the dense first pass."""
+    L, F, log2_T, S, step = 4, 2, 14, 64, 4.0 / 64
+    to = lambda x: x.to(dev)
+    oracle, hr, o, d, noise, bg, gt, emb = _setup(host, L, F, log2_T, S, step, 5, 0.0, 41)
+    colors, depths, weights, idx = hr.render(to(o[:0]), to(d[:0]), to(emb[:0]), "train", to(noise[:0]),
+                                             to(bg[:0]))
+    assert tuple(colors.shape) == (0, 3) and tuple(depths.shape) == (0,) and tuple(weights.shape) == (0,)
+    for n_rays, bias0 in ((1, 0.0), (5, 30.0)):
+        oracle, hr, o, d, noise, bg, gt, emb = _setup(host, L, F, log2_T, S, step, n_rays, bias0, 43 + n_rays)
+        with torch.no_grad():
+            res = oracle.render(o, d, emb, R.TRAIN, noise, bg)
+        if bias0 > 20:
+            assert int(res.idx_start_end[:, 1].max() - res.idx_start_end[:, 0].min()) == res.weights.numel()
+            assert res.weights.numel() <= 2 * n_rays          # one or two samples survive per ray
+        for dense in (0, 1):
+            hr.set_dense_first_pass(dense)
+            colors, depths, weights, idx = hr.render(to(o), to(d), to(emb), "train", to(noise), to(bg))
+            assert torch.equal(idx.cpu(), res.idx_start_end)
+            _close(colors.detach().cpu(), res.colors, 1e-4)
+            _close(depths.detach().cpu(), res.depths, 1e-4)
+            _close(weights.detach().cpu(), res.weights, 1e-4)
+
+
 @pytest.mark.parametrize("margin_path", [False, True])
 def test_dense_pass_guess_changes_nothing(host, dev, margin_path):
     """The dense first pass shades all samples on the guess that nothing terminates -- small chunks
