@@ -44,9 +44,10 @@ constexpr int kMaxPieces = 6;          // f16 pieces per combined sum before the
 // inside a wave at the coarsest levels), so it must shrink the record stream a lot to pay:
 constexpr int kCombineMinRunQ8 = 5 * 256;  // mean samples per level-0-scaled cell along a ray (x256)
 constexpr int kCombinePaysAt = 4500;       // ... or records saved per tile-level, predicted
-constexpr int kCombineDenseTile = 6000;    // level 0 is tried when the tile has this many non-zero
-                                           // contributions (of 8192): that is where plain binning
-                                           // overflows its queues at the coarse levels
+constexpr int kCombineRepeats = 448;       // ... or lanes (of the 768 that have four lanes before them in
+                                           // their DPP row) with a gradient above the f16 underflow whose
+                                           // level-0 cell is that of one of those four: samples piled
+                                           // onto few cells without forming runs
 constexpr int kSplitBlock = 512;       // pass B: four workgroups per CU (it is latency-bound)
 constexpr int kSplitQueueWords = 9216;   // 36 KiB: four workgroups per CU
 constexpr int kSplitRegions = 2;       // regions a wave of pass B ingests per round
@@ -264,44 +265,32 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
     const LevelParams lp0 = load_level(primes, bias, mul, 0);
     const int cx = (int)floorf(fmaf(x, lp0.mul, lp0.bx)), cy = (int)floorf(fmaf(y, lp0.mul, lp0.by)),
               cz = (int)floorf(fmaf(z, lp0.mul, lp0.bz));
-    const int px = dpp_get_i<0x138, 0xf, 0xf>(cx), py = dpp_get_i<0x138, 0xf, 0xf>(cy),
-              pz = dpp_get_i<0x138, 0xf, 0xf>(cz);
+    // (one packed id per cell for the comparisons: 10 bits per axis tell neighbouring samples apart;
+    // every instruction here is executed by all 16 waves of a tile that has the CU to itself)
+    const int cid = (cx & 1023) | ((cy & 1023) << 10) | ((cz & 1023) << 20);
     const bool has_prev = valid && lane > 0;
     const unsigned long long m_prev = __ballot(has_prev);
-    const unsigned long long m_same = __ballot(has_prev && cx == px && cy == py && cz == pz);
-    // ... and how many of the tile's 8192 level-0 contributions are non-zero?  (Gradients of
-    // samples that barely contribute underflow the f16 scale and are never binned.)
-    uint32_t n_nz0 = 0u;
-    {
-      bool any0 = false;
-      float gk0[F];
+    const unsigned long long m_same = __ballot(has_prev && cid == dpp_get_i<0x138, 0xf, 0xf>(cid));
+    // ... or do the samples pile onto a few cells without forming runs?  (Rays that stop right in
+    // front of one camera keep three or four samples each, all in the same two or three level-0
+    // cells: A B B B A B B B ...  Plain binning sends such a tile's 2400 contributions to a dozen
+    // rows, overflows its queues and ends in same-address global atomics, 80 us per tile and level.)
+    // A lane repeats if its cell is that of one of the four lanes before it (16-lane DPP rows).
+    const bool repeat = valid && (lane & 15) >= 4 &&  // (the first lanes of a DPP row see zeros)
+                        (cid == dpp_get_i<0x111, 0xf, 0xf>(cid) || cid == dpp_get_i<0x112, 0xf, 0xf>(cid) ||
+                         cid == dpp_get_i<0x113, 0xf, 0xf>(cid) || cid == dpp_get_i<0x114, 0xf, 0xf>(cid));
+    // (only worth acting on when the gradient is dense as well: a point whose scaled gradient reaches
+    // 2^-16 keeps nearly all of its 8 corner products above the f16 underflow, one far below keeps
+    // none -- the bench's dense regime has this geometry too, but 90 % of its products underflow and
+    // combining them is a loss.  An estimate: counting the products costs a level-0 hash per tile.)
+    float big = 0.f;
 #pragma unroll
-      for (int k = 0; k < F; k++) {
-        gk0[k] = round_f16(g_cur[k] * a.grad_scale);
-        any0 |= (gk0[k] != 0.f);
-      }
-      if (valid && any0) {
-        uint32_t row0[8];
-        float w0[8];
-        corner_rows_and_weights<POW2>(x, y, z, lp0, a.T, row0, w0);
-#pragma unroll
-        for (int d = 0; d < 8; d++) {
-          bool nz = false;
-#pragma unroll
-          for (int k = 0; k < F; k++) {
-            float c = gk0[k] * w0[d];
-            asm volatile("" : "+v"(c));
-            nz |= (__half_as_ushort(__float2half_rn(c)) & 0x7fffu) != 0;
-          }
-          n_nz0 += nz ? 1u : 0u;
-        }
-      }
-    }
-    const uint32_t nz_wave = (uint32_t)__builtin_amdgcn_readlane(wave_incl_scan_i32((int)n_nz0), 63);
+    for (int k = 0; k < F; k++) big = fmaxf(big, fabsf(g_cur[k] * a.grad_scale));
+    const unsigned long long m_repeat = __ballot(repeat && big >= 1.52587890625e-05f);
     if (lane == 0) {
       atomicAdd(&comb_state[2], (uint32_t)__popcll(m_same));
       atomicAdd(&comb_state[3], (uint32_t)__popcll(m_prev));
-      atomicAdd(&comb_state[1], nz_wave);
+      atomicAdd(&comb_state[5], (uint32_t)__popcll(m_repeat));
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -310,12 +299,12 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       // quotient itself only matters to a tile that combines (a 64-bit division is ~150 dependent
       // instructions of this one thread while 1023 wait)
       const uint64_t lanes_q8 = (uint64_t)(comb_state[3] + kWaves) << 8;
-      const bool on = lanes_q8 >= (uint64_t)kCombineMinRunQ8 * breaks ||
-                      comb_state[1] >= (uint32_t)kCombineDenseTile;
+      // (at most 768 of 1024 lanes can repeat; 640 = five in six of those with a look-back)
+      const bool on = lanes_q8 >= (uint64_t)kCombineMinRunQ8 * breaks || comb_state[5] >= (uint32_t)kCombineRepeats;
       comb_state[0] = on ? 1u : 0u;
       if (on) comb_state[4] = (uint32_t)(lanes_q8 / breaks);
       if (a.stats) {
-        atomicAdd(a.stats + 3, comb_state[1]);
+        atomicAdd(a.stats + 3, comb_state[5]);
         atomicAdd(a.stats + 7, 1u);
       }
     }
@@ -390,7 +379,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
     };
     // wave w copies the queues of buckets w, w+16, ... to their workspace regions and records the
     // counts ([level][bucket][tile] so that pass B / C read them coalesced)
-    auto flush = [&](int cap, int64_t tile_g) {
+    auto flush = [&](int cap, int64_t tile_g, bool watch_overflow) {
       uint32_t * region0 =
         ws_records + ((size_t)l * n_tiles_g + tile_g) * a.n_buckets * (size_t)a.qcap * KW;
       if constexpr (!Rec<F>::kSoA) {
@@ -402,10 +391,18 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
           // by instruction issue and the flush was its largest piece (bench workload: the whole
           // backward 2.27 -> 2.11 ms; full queues, 512 records per wave, lose 2-5 %).
           uint32_t c[4];
+          bool over = false;  // (scalar: the counts are wave-uniform)
 #pragma unroll
-          for (int u = 0; u < 4; u++)
-            c[u] = (uint32_t)__builtin_amdgcn_readfirstlane(
-              (int)min(qcount[wave + kWaves * u], (uint32_t)cap));
+          for (int u = 0; u < 4; u++) {
+            const uint32_t asked = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcount[wave + kWaves * u]);
+            over |= asked > (uint32_t)cap;
+            c[u] = min(asked, (uint32_t)cap);
+          }
+          // a queue overflowed (its records left as global atomics): this tile's contributions pile
+          // onto few rows here (e.g. the samples of rays that stop right in front of one camera: a
+          // dozen rows per tile and level, 80 us of same-address atomics) -- combine from the next
+          // level on
+          if (watch_overflow && over && lane == 0) comb_state[0] = 1u;
           const uint32_t p1 = c[0], p2 = p1 + c[1], p3 = p2 + c[2], total = p3 + c[3];
           const uint2 * src = reinterpret_cast<const uint2 *>(queue) + (uint32_t)wave * (uint32_t)cap;
           uint2 * dst = reinterpret_cast<uint2 *>(region0) + (uint32_t)wave * (uint32_t)a.qcap;
@@ -562,7 +559,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
         }
       }
       __syncthreads();
-      flush(a.qcap_comb, tile);
+      flush(a.qcap_comb, tile, false);
       // Combine the next level too?  Yes while the sampling is still dense relative to its cells, or
       // while the records saved (measured here, scaled by the ~1.6x more distinct rows a finer level
       // has) outweigh the cost of the mode.  Finer levels only get worse: once off, it stays off.
@@ -580,7 +577,11 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
           const float run_next = (float)comb_state[4] * (mul[0] / mul[ln]);
           const bool dense = run_next >= (float)kCombineMinRunQ8;
           const bool pays = (float)n_nz_tile - 1.6f * (float)e >= (float)kCombinePaysAt;
-          if (!(dense || pays)) comb_state[0] = 0u;
+          // ... or while the tile's contributions pile onto few rows (eight or more per row: the
+          // samples of rays that stop right in front of one camera; plain binning would overflow
+          // its queues into same-address global atomics there, 80 us per tile and level)
+          const bool hot = e > 0u && n_nz_tile >= 8u * e;
+          if (!(dense || pays || hot)) comb_state[0] = 0u;
         }
       }
     } else {
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
           }
           __syncthreads();
         }
-        flush(a.qcap, tile * a.groups + g);
+        flush(a.qcap, tile * a.groups + g, comb_allowed);
       }
     }
 #pragma unroll

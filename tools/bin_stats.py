@@ -22,7 +22,7 @@ def report(cdll, stats, L, out=sys.stdout):
     cdll.f2n_debug_bin_stats(None)
     st = stats.cpu()
     if int(st[1, 3]):
-        print("    %d tiles, %.0f non-zero level-0 contributions per tile" % (int(st[1, 3]), int(st[0, 3]) / int(st[1, 3])),
+        print("    %d tiles, %.0f lanes per tile repeat a level-0 cell of the four lanes before them" % (int(st[1, 3]), int(st[0, 3]) / int(st[1, 3])),
               file=out)
     for l in range(L):
         if not int(st[l, 0]) and (int(st[l, 2]) or int(st[l, 3])):
