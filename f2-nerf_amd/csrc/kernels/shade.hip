@@ -499,7 +499,7 @@ extern "C" int f2n_shade_fwd(
   if (!enc_cm || !dirs || !w_h || !b_h || !w1 || !b1 || !w2 || !b2 || !logit || !rgb)
     return F2N_E_INVALID_ARG;
   // matrix-core forward (shade_mfma.hip) unless F2N_OPT_SHADE_FWD asks for the one-sample-per-lane
-  // kernel below (A/B measurements) or n is beyond its 32-bit offsets
+  // kernel below (A/B measurements) or n is beyond its 32-bit per-sample offsets (2^28 samples)
   if (f2n_get_option(F2N_OPT_SHADE_FWD) == 0 && f2n_detail::shade_bwd_mfma_supports(64, n))
     return f2n_detail::launch_shade_fwd_mfma(
       enc_cm, C, dirs, sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, logit, rgb, pre_cm, n,

@@ -100,15 +100,29 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // row[byte_off / 4] with a wave-uniform row pointer: global_load_dword v, v_off, s[row:row+1]
-template <typename T>
-__device__ __forceinline__ T ld_row(const T * row, uint32_t byte_off)
+// (Off = uint32_t: the saddr + 32-bit voffset form above; uint64_t, the WIDE kernels for C * n * 4 >=
+// 2^32: a 64-bit add per access and the vaddr form -- ~6 % slower, against the 2-3x of falling back
+// to the vector kernels)
+template <typename T, typename Off>
+__device__ __forceinline__ T ld_row(const T * row, Off byte_off)
 {
   return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(row) + byte_off);
 }
-__device__ __forceinline__ void st_row(float * row, uint32_t byte_off, float v)
+template <typename Off>
+__device__ __forceinline__ void st_row(float * row, Off byte_off, float v)
 {
   *reinterpret_cast<float *>(reinterpret_cast<char *>(row) + byte_off) = v;
 }
+template <bool WIDE>
+struct RowOffset
+{
+  typedef uint32_t type;
+};
+template <>
+struct RowOffset<true>
+{
+  typedef uint64_t type;
+};
 
 // Pins global loads where they are written: without it the scheduler sinks them to their first use,
 // ~200 MFMAs later, and the wave then waits a full memory latency there.
@@ -134,7 +148,7 @@ __device__ __forceinline__ float quarter_sum(float v)
   return v;
 }
 
-template <int C, int V>
+template <int C, int V, bool WIDE>
 __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
   const float * __restrict__ enc, const float * __restrict__ dirs,
   const int32_t * __restrict__ sample_img, const float * __restrict__ p_w_h,
@@ -206,7 +220,8 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
   }
   auto W = [&](int slot) { return kWReg ? wreg[kWReg ? slot : 0] : wop[slot * 64]; };
   // byte offsets of this quarter's first enc / d_enc row (quarter q owns channels q*kS1.., rows 4q..)
-  const uint32_t cE = (uint32_t)((int64_t)(q * kS1) * n * 4), cD = (uint32_t)((int64_t)(4 * q) * n * 4);
+  using Off = typename RowOffset<WIDE>::type;
+  const Off cE = (Off)((int64_t)(q * kS1) * n * 4), cD = (Off)((int64_t)(4 * q) * n * 4);
   const bool has_emb = (p_emb != nullptr) && (sample_img != nullptr);
 
   // per-lane accumulators that live across all strides of this wave
@@ -650,7 +665,7 @@ struct FShape
   static constexpr int kLdsFloats = kWFloats + kWaves * kWaveFloats;
 };
 
-template <int C>
+template <int C, bool WIDE>
 __global__ __launch_bounds__(FShape<C>::kWaves * 64) void shade_fwd_mfma_kernel(
   const float * __restrict__ enc, const float * __restrict__ dirs,
   const int32_t * __restrict__ sample_img, const float * __restrict__ p_w_h,
@@ -687,7 +702,8 @@ __global__ __launch_bounds__(FShape<C>::kWaves * 64) void shade_fwd_mfma_kernel(
   const int q = lane >> 4, m = lane & 15;
   float * XS = lds_all + S::kWFloats + wave * S::kWaveFloats;  // SH rows 0..15 of this wave
   const float * wop = lds_w + lane;
-  const uint32_t cE = (uint32_t)((int64_t)(q * kS1) * n * 4);
+  using Off = typename RowOffset<WIDE>::type;
+  const Off cE = (Off)((int64_t)(q * kS1) * n * 4), cP = (Off)((int64_t)(4 * q) * n * 4);
   const bool has_emb = (p_emb != nullptr) && (sample_img != nullptr);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -791,8 +807,7 @@ __global__ __launch_bounds__(FShape<C>::kWaves * 64) void shade_fwd_mfma_kernel(
           if (vT[T]) {
 #pragma unroll
             for (int r = 0; r < 4; r++)
-              st_row(pre_out + (int64_t)(16 * M + r) * n, offS[T] + (uint32_t)((int64_t)(4 * q) * n * 4),
-                     pre[T][r]);
+              st_row(pre_out + (int64_t)(16 * M + r) * n, offS[T] + cP, pre[T][r]);
           }
       }
 #pragma unroll
@@ -818,7 +833,9 @@ namespace f2n_detail
 
 bool shade_bwd_mfma_supports(int C, int64_t n)
 {
-  return (C == 8 || C == 16 || C == 32 || C == 64) && (int64_t)C * n < ((int64_t)1 << 30);
+  // (per-sample offsets such as 12 s for d_rgb stay 32-bit: n < 2^28; the row offsets C n 4 are
+  // 32-bit below 2^30 elements and 64-bit, the WIDE kernels, above)
+  return (C == 8 || C == 16 || C == 32 || C == 64) && n < ((int64_t)1 << 28);
 }
 
 int launch_shade_bwd_mfma(
@@ -831,22 +848,24 @@ int launch_shade_bwd_mfma(
   const int64_t n_strides = (n + 63) / 64;
   // the embedding rows are read as float4
   if (app_emb && (reinterpret_cast<uintptr_t>(app_emb) & 15u)) return F2N_E_INVALID_ARG;
-  if ((int64_t)C * n >= ((int64_t)1 << 30)) return F2N_E_UNSUPPORTED;  // 32-bit byte offsets
+  if (n >= ((int64_t)1 << 28)) return F2N_E_UNSUPPORTED;  // 32-bit per-sample offsets
+  const bool wide = (int64_t)C * n >= ((int64_t)1 << 30);   // row offsets beyond 32 bits
   const int variant = f2n_get_option(F2N_OPT_SHADE_VARIANT);
-#define F2N_LAUNCH_MFMA_V(CC, VV)                                                                    \
+#define F2N_LAUNCH_MFMA_V(CC, VV, WW)                                                                \
   {                                                                                                  \
     constexpr int kW = MShape<CC>::kWaves;                                                             \
     const unsigned grid = (unsigned)std::min<int64_t>(256, (n_strides + kW - 1) / kW);               \
     hipLaunchKernelGGL(                                                                              \
-      (shade_bwd_mfma_kernel<CC, VV>), dim3(grid), dim3(kW * 64), 0, stream, enc_cm, dirs, sample_img,   \
-      w_h, b_h, w1, b1, w2, b2, app_emb, d_logit, d_rgb, d_enc_cm, g_w_h, g_b_h, g_w1, g_b1, g_w2,    \
-      g_b2, g_app_emb, n);                                                                           \
+      (shade_bwd_mfma_kernel<CC, VV, WW>), dim3(grid), dim3(kW * 64), 0, stream, enc_cm, dirs,        \
+      sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, d_logit, d_rgb, d_enc_cm, g_w_h, g_b_h, g_w1,    \
+      g_b1, g_w2, g_b2, g_app_emb, n);                                                               \
   }
-#define F2N_LAUNCH_MFMA(CC)                  \
-  switch (variant) {                         \
-    case 1: F2N_LAUNCH_MFMA_V(CC, 1) break;  \
-    default: F2N_LAUNCH_MFMA_V(CC, 0) break; \
-  }
+#define F2N_LAUNCH_MFMA(CC)                                \
+  if (wide) F2N_LAUNCH_MFMA_V(CC, 0, true)                 \
+  else switch (variant) {                                  \
+      case 1: F2N_LAUNCH_MFMA_V(CC, 1, false) break;       \
+      default: F2N_LAUNCH_MFMA_V(CC, 0, false) break;      \
+    }
   switch (C) {
     case 8: F2N_LAUNCH_MFMA(8) break;
     case 16: F2N_LAUNCH_MFMA(16) break;
@@ -867,15 +886,18 @@ int launch_shade_fwd_mfma(
 {
   const int64_t n_strides = (n + 63) / 64;
   if (app_emb && (reinterpret_cast<uintptr_t>(app_emb) & 15u)) return F2N_E_INVALID_ARG;
-  if ((int64_t)64 * n >= ((int64_t)1 << 30)) return F2N_E_UNSUPPORTED;  // 32-bit byte offsets (pre_cm)
-#define F2N_LAUNCH_FWD(CC)                                                                         \
+  if (n >= ((int64_t)1 << 28)) return F2N_E_UNSUPPORTED;  // 32-bit per-sample offsets
+  const bool wide = (int64_t)(pre_cm ? 64 : C) * n >= ((int64_t)1 << 30);  // row offsets beyond 32 bits
+#define F2N_LAUNCH_FWD_W(CC, WW)                                                                   \
   {                                                                                                \
     constexpr int kW = FShape<CC>::kWaves;                                                         \
     const unsigned grid = (unsigned)std::min<int64_t>(256, (n_strides + kW - 1) / kW);             \
     hipLaunchKernelGGL(                                                                            \
-      (shade_fwd_mfma_kernel<CC>), dim3(grid), dim3(kW * 64), 0, stream, enc_cm, dirs, sample_img, \
-      w_h, b_h, w1, b1, w2, b2, app_emb, logit, rgb, pre_cm, n);                                   \
+      (shade_fwd_mfma_kernel<CC, WW>), dim3(grid), dim3(kW * 64), 0, stream, enc_cm, dirs,         \
+      sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, logit, rgb, pre_cm, n);                       \
   }
+#define F2N_LAUNCH_FWD(CC) \
+  if (wide) F2N_LAUNCH_FWD_W(CC, true) else F2N_LAUNCH_FWD_W(CC, false)
   switch (C) {
     case 8: F2N_LAUNCH_FWD(8) break;
     case 16: F2N_LAUNCH_FWD(16) break;
@@ -884,6 +906,7 @@ int launch_shade_fwd_mfma(
     default: return F2N_E_UNSUPPORTED;
   }
 #undef F2N_LAUNCH_FWD
+#undef F2N_LAUNCH_FWD_W
   return f2n_launch_status();
 }
 

@@ -96,3 +96,58 @@ def test_shade_fwd_bwd(capi, dev, C, n, with_emb):
         torch.testing.assert_close(G["w1"].cpu(), 2 * r_g["w1"], rtol=1e-3,
                                    atol=4e-4 * float(r_g["w1"].abs().max()),
                                    msg=lambda m: tag(m, "w1 accumulate"))
+
+
+def test_shade_mfma_wide_rows(capi, dev):
+    """Above 2^30 elements of encoding (C n 4 >= 2^32 bytes) the matrix-core kernels switch to 64-bit
+    row offsets (WIDE): same results as the vector kernels, which never had the limit, on 34 M samples
+    -- spot-checked where 32-bit offsets would have wrapped (the last quarter's rows, the far end)."""
+    C, n, E = 32, (1 << 25) + (1 << 20) + 77, 5
+    assert C * n >= 1 << 30
+    g = torch.Generator(device=dev).manual_seed(5)
+    enc_cm = (torch.randn(C, n, device=dev, generator=g) * 0.1).to(torch.float16).float()
+    dirs = torch.randn(n, 3, device=dev, generator=g)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    img = (torch.arange(n, device=dev) // 4099 % E).to(torch.int32)
+    gc = torch.Generator().manual_seed(6)
+    P = {"w_h": torch.randn(16, C, generator=gc) * 0.3, "b_h": torch.randn(16, generator=gc) * 0.1,
+         "w1": torch.randn(64, 32, generator=gc) * 0.3, "b1": torch.randn(64, generator=gc) * 0.1,
+         "w2": torch.randn(3, 64, generator=gc) * 0.3, "b2": torch.randn(3, generator=gc) * 0.1,
+         "emb": torch.randn(E, 16, generator=gc) * 0.1}
+    Pd = {k: v.to(dev).contiguous() for k, v in P.items()}
+    d_logit = torch.randn(n, device=dev, generator=g)
+    d_rgb = torch.randn(n, 3, device=dev, generator=g)
+    out = {}
+    for route in ("mfma", "vector"):
+        capi.set_option("SHADE_FWD", 1 if route == "vector" else 0)
+        capi.set_option("SHADE_BWD", 1 if route == "vector" else 0)
+        logit = torch.full((n,), 7.0, device=dev)
+        rgb = torch.full((n, 3), 7.0, device=dev)
+        capi.call("shade_fwd", enc_cm, C, dirs, img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"], Pd["w2"],
+                  Pd["b2"], Pd["emb"], logit, rgb, None, n)
+        d_enc = torch.full((C, n), 7.0, device=dev)
+        G = {k: torch.zeros_like(v) for k, v in Pd.items()}
+        capi.call("shade_bwd", enc_cm, C, dirs, img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"], Pd["w2"],
+                  Pd["b2"], Pd["emb"], d_logit, d_rgb, d_enc, G["w_h"], G["b_h"], G["w1"], G["b1"],
+                  G["w2"], G["b2"], G["emb"], None, n)
+        out[route] = (logit, rgb, d_enc, G)
+    capi.set_option("SHADE_FWD", 0)
+    capi.set_option("SHADE_BWD", 0)
+    a, b = out["mfma"], out["vector"]
+    torch.testing.assert_close(a[0], b[0], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a[1], b[1], rtol=1e-4, atol=1e-5)
+    scale = float(b[2].abs().max())
+    for rows in (slice(0, 2), slice(23, 25), slice(30, 32)):          # quarters 0, 2 / 3, 3
+        for cols in (slice(0, 4096), slice(n // 2, n // 2 + 4096), slice(n - 4096, n)):
+            d = (a[2][rows, cols] - b[2][rows, cols]).abs()
+            assert float(d.median()) <= 1e-5 * scale and int((d > 1e-3 * scale).sum()) <= 4
+    # Everywhere: equal up to the samples whose hidden pre-activation lies within rounding of zero
+    # (two summation orders put the ReLU on different sides: ~1e-6 of 2.2e9 pre-activations, each
+    # moving its sample's 32 gradient channels); a wrapped offset would corrupt whole rows instead.
+    diff = (a[2] - b[2]).abs()
+    bad = int((diff > 1e-3 * scale).sum())
+    assert bad <= 2e-4 * diff.numel(), (bad, diff.numel())
+    assert float(diff.mean()) <= 1e-6 * scale
+    for k in ("w_h", "b_h", "w1", "b1", "w2", "b2", "emb"):
+        ref = b[3][k]
+        torch.testing.assert_close(a[3][k], ref, rtol=2e-3, atol=1e-3 * float(ref.abs().max()))
