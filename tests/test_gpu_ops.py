@@ -247,6 +247,44 @@ def test_hash_bwd_binned_combine(capi, dev, L, F, log2_T, S):
     assert (out[0] - out[1]).abs().max().item() <= 1e-6 * scale
 
 
+def test_hash_bwd_binned_hot_spot(capi, dev):
+    """Rays that stop right in front of one camera: three or four samples each, all in the same few
+    cells, every gradient non-zero -- a tile's 8192 contributions land on a dozen rows per level.
+    Plain binning overflows its queues there (the records leave as same-address atomics); the tile
+    must notice (repeating cells / an overflowing queue), combine from then on, and stay exact: sums
+    in the combined levels are bit-equal to the oracle's exact sums up to its own f32 rounding."""
+    L, F, log2_T = 16, 2, 19
+    T = 1 << log2_T
+    fld = util.make_field(L, F, log2_T, None, seed=5)
+    g = torch.Generator().manual_seed(8)
+    n_rays = 20000
+    o = torch.tensor([0.31, -0.22, 0.17]) + torch.zeros(n_rays, 1, 3)
+    d = torch.randn(n_rays, 1, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    k = torch.randint(3, 5, (n_rays,), generator=g)                  # 3 or 4 samples per ray
+    t = (torch.arange(1, 5).float() / 32.0).reshape(1, 4, 1)
+    keep = (torch.arange(4).reshape(1, 4) < k.reshape(-1, 1)).reshape(-1)
+    pts = (o + d * t).reshape(-1, 3)[keep].contiguous()
+    n = pts.shape[0]
+    assert n >= 65536
+    grad = torch.randn(n, L * F, generator=g) * 1e-2
+    numel = fld["table"].numel()
+    ref_tg, _ = K.hash_bwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad,
+                           numel, L, F, T, fld["stride"], 128.0, parallel=True)
+    need = capi.lib().cdll.f2n_hash_bwd_workspace_bytes(n, L, F, T)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    dd = _to(dev, pts, fld["primes"], fld["bias"], fld["mul"], grad.t().contiguous())
+    scale = ref_tg.abs().max().item()
+    for combine_off in (0, 1):
+        with capi.option("BWD_COMBINE", combine_off):
+            tg = torch.zeros(numel, device=dev)
+            capi.call("hash_bwd_binned", *dd, 1, n, tg, n, L, F, T, fld["stride"], 128.0, ws, need)
+        # (with the combine off, or before a tile has noticed, overflowing records are float atomics:
+        # order-dependent in the last bits of sums of thousands of terms)
+        assert (tg.cpu() - ref_tg).abs().max().item() <= 1e-4 * scale, combine_off
+        assert ((tg.cpu() - ref_tg).norm() / ref_tg.norm()).item() < 1e-5, combine_off
+
+
 @pytest.mark.parametrize("route", ["binned", "binned_nocombine", "sliced", "atomic"])
 def test_hash_bwd_nonfinite_gradient_propagates(capi, dev, route):
     """An incoming gradient beyond the f16 range (128*g overflows to inf) must poison the rows it
