@@ -121,7 +121,7 @@ __global__ __launch_bounds__(F2N_BLOCK) void hash_fwd_raytile_kernel(
   //           reference's 1024 steps of 1/256 put up to 32 consecutive samples in one coarse cell
   //           (random training rays: neighbouring rays share nothing).
   // Decided per tile from its own points: the walk with the smaller extent touches fewer cells.
-  bool along;
+  bool along, drifted;
   {
     // Distinct cells of size c touched by one gather: across ~ (e / c + 1) for rays strung along a
     // pixel row of extent e, times the depth cloud the TRAIN jitter adds (neighbouring rays then sit
@@ -137,12 +137,59 @@ __global__ __launch_bounds__(F2N_BLOCK) void hash_fwd_raytile_kernel(
     const float e = dist(RAYS - 1, m, 0, m), e1 = dist(1, m, 0, m), sl = dist(0, SAMPLES - 1, 0, 0);
     along = !(e + 8.f * e1 < 2.f * sl);
     if (walk) along = (walk == 2);
+    // neighbouring rays more than a third of a step apart at one sample index: jittered depths
+    // (un-jittered views sit a pixel apart there, 0.06 steps: nothing to sort, 4 % to lose)
+    drifted = e1 * (float)(SAMPLES - 1) > 0.35f * sl;
+  }
+  // Across, third variant (walk 3, and the default when a tile that walks across has drifted): the tile's
+  // 64 x SAMPLES (ray, sample) pairs in DEPTH order.  TRAIN jitter lets the rays of a tile drift
+  // +-2.5 steps apart in depth by mid-ray, so "all rays at one sample index" is a cloud 5 steps deep
+  // and the mid levels (cells of 0.3-1 step) stop sharing lines; 64 pairs taken from a counting sort
+  // by depth along the middle ray (64 bins of half a step) form a slab one step thick instead.  The
+  // order of the pairs means nothing to the result.
+  __shared__ uint16_t order[RAYS * SAMPLES];
+  __shared__ uint32_t bin_at[64];
+  const bool sorted = !along && (walk == 3 || (walk == 0 && drifted));
+  if (sorted) {
+    constexpr int kPairs = RAYS * SAMPLES / 256;  // per thread
+    constexpr int mr = RAYS / 2;
+    const float ax = ptile[mr][3 * (SAMPLES - 1)] - ptile[mr][0],
+                ay = ptile[mr][3 * (SAMPLES - 1) + 1] - ptile[mr][1],
+                az = ptile[mr][3 * (SAMPLES - 1) + 2] - ptile[mr][2];
+    const float inv = 64.f / fmaxf(ax * ax + ay * ay + az * az, 1e-30f);
+    const float ox = ptile[mr][0], oy = ptile[mr][1], oz = ptile[mr][2];
+    if (threadIdx.x < 64) bin_at[threadIdx.x] = 0u;
+    __syncthreads();
+    int my_bin[kPairs];
+#pragma unroll
+    for (int i = 0; i < kPairs; i++) {
+      const int pair = threadIdx.x + 256 * i, ray = pair / SAMPLES, ks = pair % SAMPLES;
+      const float d = (ptile[ray][3 * ks] - ox) * ax + (ptile[ray][3 * ks + 1] - oy) * ay +
+                      (ptile[ray][3 * ks + 2] - oz) * az;
+      my_bin[i] = min(max((int)(d * inv), 0), 63);  // (a NaN point lands in bin 0)
+      atomicAdd(&bin_at[my_bin[i]], 1u);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int c = (int)bin_at[lane];
+      bin_at[lane] = (uint32_t)(wave_incl_scan_i32(c) - c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPairs; i++)
+      order[atomicAdd(&bin_at[my_bin[i]], 1u)] = (uint16_t)(threadIdx.x + 256 * i);
+    __syncthreads();
   }
   constexpr int kRaysPerIter = 64 / SAMPLES;  // along: rays one wave instruction covers
 #pragma unroll
   for (int j = 0; j < SAMPLES / 4; j++) {
-    const int ks = along ? (lane % SAMPLES) : (j * 4 + wave);
-    const int ray = along ? ((j * 4 + wave) * kRaysPerIter + lane / SAMPLES) : lane;
+    int ks = along ? (lane % SAMPLES) : (j * 4 + wave);
+    int ray = along ? ((j * 4 + wave) * kRaysPerIter + lane / SAMPLES) : lane;
+    if (sorted) {
+      const int pair = order[(j * 4 + wave) * 64 + lane];
+      ray = pair / SAMPLES;
+      ks = pair % SAMPLES;
+    }
     const float x = ptile[ray][3 * ks], y = ptile[ray][3 * ks + 1], z = ptile[ray][3 * ks + 2];
     uint32_t row[8];
     float w[8];

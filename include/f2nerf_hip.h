@@ -50,7 +50,8 @@ const char * f2n_status_string(int status);
 #define F2N_OPT_RAYTILE 3       /* samples per ray tile of f2n_hash_fwd_raytile: 0 auto, 16, 32     */
 #define F2N_OPT_HASH_BWD 4      /* f2n_hash_bwd route: 0 auto, 1 global atomics, 2 LDS-sliced       */
 #define F2N_OPT_BWD_COMBINE 5   /* binned backward: 0 combine coarse levels per tile, 1 never       */
-#define F2N_OPT_RAYTILE_WALK 6  /* lanes of f2n_hash_fwd_raytile: 0 chosen per tile, 1 across rays, 2 along a ray */
+#define F2N_OPT_RAYTILE_WALK 6  /* lanes of f2n_hash_fwd_raytile: 0 chosen per tile, 1 across rays at one
+                                   sample index, 2 along a ray, 3 across rays in depth order        */
 #define F2N_OPT_COUNT 7
 int f2n_set_option(int key, int value);
 int f2n_get_option(int key);

@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--points", default="rays", choices=["rays", "ball", "view", "view_sm"],
+    ap.add_argument("--points", default="rays", choices=["rays", "ball", "view", "view_sm", "view_jit"],
                     help="rays: random rays, samples of a ray consecutive; view: 65536 consecutive pixels of "
                          "an 800-wide pinhole view (focal 1111, camera at distance 1), ray-major as the "
                          "renderer emits them; view_sm: the same points sample-major (lane = adjacent pixel)")
@@ -72,7 +72,7 @@ def main():
         nrm = p.norm(dim=1, keepdim=True)
         pts = torch.where(nrm <= 1, p, (2 - 1 / nrm) * p / nrm).contiguous()
         n = pts.shape[0]
-    elif args.points in ("view", "view_sm"):
+    elif args.points in ("view", "view_sm", "view_jit"):
         S, R, W, f = 128, n // 128, 800, 1111.1
         pix = torch.arange(R, device=dev)
         i, j = (pix // W).float(), (pix % W).float()
@@ -81,6 +81,8 @@ def main():
         d = d / d.norm(dim=1, keepdim=True)
         o = torch.tensor([1.0, 0.0, 0.0], device=dev).expand(R, 3)
         t = ((torch.arange(S, device=dev).float() + 0.5) * (4.0 / S)).reshape(1, S, 1)
+        if args.points == "view_jit":                          # TRAIN: every step scaled by U[0.5, 1.5)
+            t = ((torch.rand(R, S, device=dev, generator=g) + 0.5).cumsum(1) * (4.0 / S)).reshape(R, S, 1)
         p = (o[:, None] + d[:, None] * t)                      # [R, S, 3]
         if args.points == "view_sm":
             p = p.transpose(0, 1)                              # [S, R, 3]
@@ -101,9 +103,9 @@ def main():
         med, best = timeit(lambda: capi.call("hash_fwd", pts, table16, primes, bias, mul, out, ldp, ldc,
                                              None, n, L, F, T, stride), args.reps)
         print("  %-28s %8.3f ms (best %8.3f)  %7.1f GB/s algorithmic" % (name, med, best, n * bytes_fwd / med / 1e6))
-    if args.points in ("rays", "view") and n % 128 == 0:
+    if args.points in ("rays", "view", "view_jit") and n % 128 == 0:
         S_rt = 1024 if args.config == "c4" else 128
-        for walk, name in ((0, "auto"), (1, "across rays"), (2, "along a ray")):
+        for walk, name in ((0, "auto"), (1, "across, one sample index"), (3, "across, depth order"), (2, "along a ray")):
             capi.set_option("RAYTILE_WALK", walk)
             med, best = timeit(lambda: capi.call("hash_fwd_raytile", pts, table16, primes, bias, mul, out_cm,
                                                  n // S_rt, S_rt, L, F, T, stride), args.reps)
