@@ -139,7 +139,9 @@ __global__ __launch_bounds__(F2N_BLOCK) void hash_fwd_raytile_kernel(
     if (walk) along = (walk == 2);
     // neighbouring rays more than a third of a step apart at one sample index: jittered depths
     // (un-jittered views sit a pixel apart there, 0.06 steps: nothing to sort, 4 % to lose)
-    drifted = e1 * (float)(SAMPLES - 1) > 0.35f * sl;
+    // (three pairs of neighbours: one pair is that close by chance in a fifth of the jittered tiles)
+    const float apart = fmaxf(e1, fmaxf(dist(RAYS / 2 + 1, m, RAYS / 2, m), dist(RAYS - 1, m, RAYS - 2, m)));
+    drifted = apart * (float)(SAMPLES - 1) > 0.35f * sl;
   }
   // Across, third variant (walk 3, and the default when a tile that walks across has drifted): the tile's
   // 64 x SAMPLES (ray, sample) pairs in DEPTH order.  TRAIN jitter lets the rays of a tile drift
