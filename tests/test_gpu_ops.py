@@ -71,9 +71,13 @@ def test_hash_fwd_raytile_matches_oracle(capi, dev, L, F, T, n_rays, S):
     ref, _ = K.hash_fwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], L, F, T,
                         fld["stride"], want_idx=True)
     d = _to(dev, pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"])
-    out = torch.full((L * F, n), 7.0, device=dev)
-    capi.call("hash_fwd_raytile", *d, out, n_rays, S, L, F, T, fld["stride"])
-    _assert_hash_values(out.t().contiguous().cpu(), ref)
+    # every way a tile can be walked (chosen per tile / across at one sample index / along a ray /
+    # across in depth order) computes the same values
+    for walk in (0, 1, 2, 3):
+        with capi.option("RAYTILE_WALK", walk):
+            out = torch.full((L * F, n), 7.0, device=dev)
+            capi.call("hash_fwd_raytile", *d, out, n_rays, S, L, F, T, fld["stride"])
+        _assert_hash_values(out.t().contiguous().cpu(), ref)
     with pytest.raises(capi.F2NError):   # S must be a multiple of 16
         capi.call("hash_fwd_raytile", *d, out, n_rays, S - 1, L, F, T, fld["stride"])
 
