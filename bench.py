@@ -67,6 +67,10 @@ def parse_args():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="kernel route for A/B measurements (f2n_set_option), e.g. BWD_COMBINE=1; "
                          "recorded in the JSON line")
+    ap.add_argument("--pixel-tiles", type=int, default=8, metavar="B",
+                    help="order in which a view's pixels are handed to the renderer: BxB pixel tiles (the "
+                         "Renderer's own traversal in render_image; default 8) or 0 = row by row.  Same "
+                         "rays and chunk sizes either way; falls back to rows when B does not divide the image")
     ap.add_argument("--debug-bin-stats", action="store_true",
                     help="print the binned backward's per-level counters of the timed steps on stderr")
     ap.add_argument("--dry-run", action="store_true",
@@ -172,12 +176,12 @@ def workload_key(args):
     quoted for another."""
     default = (args.height == 800 and args.width == 800 and args.samples == 128 and args.levels == 16 and
                args.channels == 2 and args.log2_table == 19 and args.chunk == 65536 and args.rays == 0 and
-               args.regime == "dense")
+               args.regime == "dense" and args.pixel_tiles == 8)
     if default:
         return "c2"
-    return "%dx%d_S%d_L%d_F%d_T%d_chunk%d_rays%d_%s" % (
+    return "%dx%d_S%d_L%d_F%d_T%d_chunk%d_rays%d_%s_tiles%d" % (
         args.height, args.width, args.samples, args.levels, args.channels, args.log2_table, args.chunk,
-        args.rays, args.regime)
+        args.rays, args.regime, args.pixel_tiles)
 
 
 def pmc_traffic(op, workload_key="c2"):
@@ -582,6 +586,10 @@ def main():
     for s in range(total_steps):
         v = pkg.sharding.view_for(s, rank, world, args.n_images)
         o, d = view_rays(H, poses[v], intr, args.height, args.width)
+        if args.pixel_tiles > 1 and args.height % args.pixel_tiles == 0 and args.width % args.pixel_tiles == 0:
+            B, hh, ww = args.pixel_tiles, args.height, args.width
+            ids = torch.arange(hh * ww, device=dev).view(hh // B, B, ww // B, B).permute(0, 2, 1, 3).reshape(-1)
+            o, d = o[ids].contiguous(), d[ids].contiguous()
         if args.rays > 0:
             pick = torch.randint(0, o.shape[0], (args.rays,), device=dev)
             o, d = o[pick].contiguous(), d[pick].contiguous()
@@ -713,6 +721,10 @@ def main():
                                    "%d samples/ray, L=%d F=%d T=2^%d, %d-ray chunks, TRAIN render + "
                                    "loss + backward (optimizer excluded)"
                                    % (S, L, F, args.log2_table, args.chunk),
+                       "pixel_order": ("%dx%d tiles" % (args.pixel_tiles, args.pixel_tiles)
+                                       if args.rays == 0 and args.pixel_tiles > 1 and
+                                       args.height % args.pixel_tiles == 0 and args.width % args.pixel_tiles == 0
+                                       else ("rows" if args.rays == 0 else "random")),
                        "regime": args.regime, "rays_per_step_per_gpu": n_rays_view,
                        "samples_per_ray_kept": n_samples_total / (n_rays_view * args.steps),
                        "sharding": "one view per rank per step, RCCL all-reduce of {sq_err, n} only"},

@@ -244,6 +244,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     .def("set_fused_shade", [](Renderer & r, bool f) { r.options_.fused_shade = f; })
     .def("set_dense_first_pass", [](Renderer & r, int m) { r.options_.dense_first_pass = m; })
     .def("set_speculate_dense", [](Renderer & r, bool f) { r.options_.speculate_dense = f; })
+    .def("set_pixel_tiles", [](Renderer & r, int b) { r.options_.pixel_tiles = b; })
     .def("set_margin_min_samples", [](Renderer & r, int64_t n) { r.options_.margin_min_samples = n; })
     .def_readonly("last_kept_fraction", &Renderer::last_kept_fraction_)
     .def_readonly("last_n_samples", &Renderer::last_n_samples_)

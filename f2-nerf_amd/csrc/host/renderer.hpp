@@ -65,6 +65,7 @@ struct RendererOptions
   // instead of twice when little terminates; march: stop rays in-kernel, re-encode survivors.
   int dense_first_pass = -1;
   float early_stop_trans = 1e-4f;  // renderer.cpp:68
+  int pixel_tiles = 8;             // render_image traverses the view in tiles of this many pixels squared (0: rows)
   // Dense first pass: when the previous chunk kept every sample, shade all samples first and accept
   // that as the result if no ray comes near the early-stop threshold (see render_fused); results are
   // identical either way.

@@ -263,6 +263,19 @@ def test_validate_render_and_image(host, dev):
         img, dep = hr.render_image(pose.to(dev), K.to(dev), h, w, 16)
     assert tuple(img.shape) == (h, w, 3) and tuple(dep.shape) == (h, w, 3)
     _close(img.cpu().reshape(-1, 3), ref.colors.clip(0, 1), 1e-4)
+    # the order in which render_image walks the pixels (8x8 tiles by default, 2x2 tiles, rows) is its
+    # own business: the image is the same (this 6x8 one is not divisible by 8: rows)
+    h2, w2 = 16, 24
+    K2 = torch.tensor([[40., 0, 12], [0, 40., 8], [0, 0, 1]])
+    images = []
+    for tiles in (8, 2, 0):
+        hr.set_pixel_tiles(tiles)
+        with torch.no_grad():
+            images.append(hr.render_image(pose.to(dev), K2.to(dev), h2, w2, 100))
+    hr.set_pixel_tiles(8)
+    for img_t, dep_t in images[1:]:
+        torch.testing.assert_close(img_t, images[0][0], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(dep_t, images[0][1], rtol=1e-5, atol=1e-6)
 
 
 def test_pose_gradient_path(host, dev):
