@@ -5,7 +5,9 @@ One "step" = one full 800x800 synthetic view (640 000 rays) pushed through
 Renderer::render(TRAIN) + loss + backward in 65 536-ray chunks (BASELINE.json configs[1]:
 128 samples/ray, L=16 hash levels, F=2, T=2^19, one GPU).  The optimiser step is excluded, as in
 BASELINE.md.  Rays, step noise inputs (drawn on device per chunk, as the reference does), ground
-truth colours and all parameters are resident in HBM before the timed region starts.
+truth colours and all parameters are resident in HBM before the timed region starts.  A view's rays
+are handed over in 8x8 pixel tiles (--pixel-tiles, the order Renderer::render_image walks a view
+in itself; 0 = row by row: same rays, same chunk sizes; the JSON line says which in config.pixel_order).
 
 Multi-GPU: `python bench.py --gpus N` starts N ranks itself (child processes through
 torch.distributed.run, before this process touches the GPU); under an external launcher
