@@ -6,8 +6,10 @@ Renderer::render(TRAIN) + loss + backward in 65 536-ray chunks (BASELINE.json co
 128 samples/ray, L=16 hash levels, F=2, T=2^19, one GPU).  The optimiser step is excluded, as in
 BASELINE.md.  Rays, step noise inputs (drawn on device per chunk, as the reference does), ground
 truth colours and all parameters are resident in HBM before the timed region starts.  A view's rays
-are handed over in 8x8 pixel tiles (--pixel-tiles, the order Renderer::render_image walks a view
-in itself; 0 = row by row: same rays, same chunk sizes; the JSON line says which in config.pixel_order).
+are handed over row by row, as the reference's render_all_rays walks a view (--pixel-tiles B: BxB
+pixel tiles instead, the order Renderer::render_image uses itself; same rays, same chunk sizes; the
+JSON line says which in config.pixel_order, and carries the 8x8-tile figure of the same build as the
+separate object "pixel_tiles_8x8" -- never as value).
 
 Multi-GPU: `python bench.py --gpus N` starts N ranks itself (child processes through
 torch.distributed.run, before this process touches the GPU); under an external launcher
@@ -17,8 +19,16 @@ RCCL all-reduce per step of {sum of squared error, value count} for the global P
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     -- the dominant hand-written kernel's algorithmic bytes / its hipEvent-timed duration
+  hash_fwd_roofline -- the same for the hash-grid gather (the kernel the north star's 40 % is about)
+  kernels.hash_bwd_nonzero -- the table-gradient kernels timed again on the same points with a
+                  gradient whose contributions are all non-zero (the headline's untrained network
+                  leaves 90 % of them below the f16 underflow); outside value
+  collective   -- backend / world size / latency of the path's one all-reduce (RCCL, also at N = 1)
+  c5           -- BASELINE config C5 (hash kernels alone, T = 2^22, F = 8) run once after the
+                  headline: roofline (backward), roofline_fwd, cpu_baseline; outside value
   cpu_baseline -- the CPU oracle (a port of the reference arranged as the reference is) timed on
                   this box's host cores on a bounded sample of the same workload (N=1 only).
+--workload c3 / c4 / c5 select the other BASELINE configs (presets of the flags below).
 """
 import argparse
 import importlib
@@ -57,22 +67,34 @@ def parse_args():
                     help="torch.distributed backend; nccl = RCCL (default). 'gloo' + --share-gpu lets "
                          "several ranks rehearse the multi-rank path on a one-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0 (rehearsal only)")
-    ap.add_argument("--workload", choices=["render", "c5"], default="render",
-                    help="render: the headline (BASELINE config C2 shape by default; C1/C3/C4 through "
-                         "--levels/--samples/--height/--width/--rays).  c5: BASELINE config C5, the "
+    ap.add_argument("--workload", choices=["render", "c2", "c3", "c4", "c5"], default="render",
+                    help="render / c2: the headline (BASELINE config C2 shape by default; C1 through "
+                         "--levels/--samples).  c3: BASELINE config C3 as BASELINE.md states it -- 120 "
+                         "poses on a 3-turn expanding spiral (r 0.2 -> 1.0, z -0.3 -> 0.3, look-ahead "
+                         "orientation), fx = fy = 1400, 1920x1080, 192 samples/ray.  c4: BASELINE config "
+                         "C4's per-GPU shape -- 512 random rays per step, 1024 samples of 1/256 (the "
+                         "reference's own batch).  c5: BASELINE config C5, the "
                          "hash-grid kernels alone (forward + backward) on 2^24 uniform points of the "
                          "radius-2 ball, T = 2^22, L = 16, F = 8, 1 GiB f16 table -- the HBM stress; "
                          "reports points/s with a roofline object per kernel")
+    ap.add_argument("--focal", type=float, default=1111.1, help="fx = fy of the synthetic cameras")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline: skip the separately timed extra legs of the default line "
+                         "(8x8 pixel tiles, non-zero-gradient table backward, config C5)")
+    ap.add_argument("--no-collective-at-1", action="store_true",
+                    help="at --gpus 1 do not create the one-rank RCCL group (the path's all-reduce then "
+                         "is skipped, as in rounds 1-2)")
     ap.add_argument("--c5-points", type=int, default=1 << 24)
     ap.add_argument("--c5-workspace-gib", type=float, default=0.0,
                     help="scratch for the binned backward (0 = the library's recommendation)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="kernel route for A/B measurements (f2n_set_option), e.g. BWD_COMBINE=1; "
                          "recorded in the JSON line")
-    ap.add_argument("--pixel-tiles", type=int, default=8, metavar="B",
-                    help="order in which a view's pixels are handed to the renderer: BxB pixel tiles (the "
-                         "Renderer's own traversal in render_image; default 8) or 0 = row by row.  Same "
-                         "rays and chunk sizes either way; falls back to rows when B does not divide the image")
+    ap.add_argument("--pixel-tiles", type=int, default=0, metavar="B",
+                    help="order in which a view's pixels are handed to the renderer: 0 = row by row (default: "
+                         "the reference's render_all_rays order, comparable with round 1 and BASELINE) or BxB "
+                         "pixel tiles (the Renderer's own traversal in render_image).  Same rays and chunk "
+                         "sizes either way; falls back to rows when B does not divide the image")
     ap.add_argument("--debug-bin-stats", action="store_true",
                     help="print the binned backward's per-level counters of the timed steps on stderr")
     ap.add_argument("--dry-run", action="store_true",
@@ -93,7 +115,42 @@ def parse_args():
                          "iterations of the reference's own shape (512 random rays per GPU drawn on the "
                          "device, 1024 samples, fwd + bwd + gradient all-reduce + fused Adam; SURVEY 8f "
                          "ranks 1, 2, 4) and report them as \"train_iteration\" -- not part of value")
-    return ap.parse_args()
+    args = ap.parse_args()
+    explicit = {a.split("=")[0] for a in sys.argv[1:] if a.startswith("--")}
+    preset = {"c3": {"height": 1080, "width": 1920, "samples": 192, "n_images": 120, "focal": 1400.0},
+              "c4": {"rays": 512, "samples": 1024}}.get(args.workload, {})
+    for k, v in preset.items():          # a preset fills in what the command line did not say
+        if "--" + k.replace("_", "-") not in explicit:
+            setattr(args, k, v)
+    return args
+
+
+def spiral_poses(n, turns=3.0, r0=0.2, r1=1.0, z0=-0.3, z1=0.3):
+    """BASELINE.md config C3 / SURVEY 8(d) "free-trajectory": n poses on an expanding spiral, each
+    camera looking ahead along the path (-z forward, y up as far as the path allows), then
+    normalised the way the reference normalises a dataset (src/dataset.cpp:77-86)."""
+    u = torch.linspace(0.0, 1.0, n, dtype=torch.float64)
+
+    def path(v):
+        th, r = 2.0 * math.pi * turns * v, r0 + (r1 - r0) * v
+        return torch.stack([r * torch.cos(th), r * torch.sin(th), z0 + (z1 - z0) * v], 1)
+
+    pos = path(u)
+    fwd = path(u + 1e-4) - pos
+    fwd = fwd / fwd.norm(dim=1, keepdim=True)
+    zc = -fwd
+    up = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64).expand(n, 3)
+    xc = torch.cross(up, zc, dim=1)
+    xc = xc / xc.norm(dim=1, keepdim=True)
+    yc = torch.cross(zc, xc, dim=1)
+    center = pos.mean(0)
+    radius = (pos - center).norm(dim=1).max()
+    pos_n = (pos - center) / radius
+    return torch.cat([torch.stack([xc, yc, zc], 2), pos_n.unsqueeze(2)], 2).float()  # [n,3,4]
+
+
+def camera_poses(args):
+    return spiral_poses(args.n_images) if args.workload == "c3" else fox_like_poses(args.n_images)
 
 
 def fox_like_poses(n, seed=2022):
@@ -178,7 +235,7 @@ def workload_key(args):
     quoted for another."""
     default = (args.height == 800 and args.width == 800 and args.samples == 128 and args.levels == 16 and
                args.channels == 2 and args.log2_table == 19 and args.chunk == 65536 and args.rays == 0 and
-               args.regime == "dense" and args.pixel_tiles == 8)
+               args.regime == "dense" and args.pixel_tiles == 0 and args.workload in ("render", "c2"))
     if default:
         return "c2"
     return "%dx%d_S%d_L%d_F%d_T%d_chunk%d_rays%d_%s_tiles%d" % (
@@ -253,9 +310,24 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
+def tiles_active(args, B=None):
+    B = args.pixel_tiles if B is None else B
+    return args.rays == 0 and B > 1 and args.height % B == 0 and args.width % B == 0
+
+
+def pixel_order(h, w, B, device="cpu"):
+    """Row-major pixel ids in the order a view is handed to the renderer: BxB tiles, or rows (B <= 1)."""
+    ids = torch.arange(h * w, device=device)
+    if B > 1:
+        ids = ids.view(h // B, B, w // B, B).permute(0, 2, 1, 3).reshape(-1)
+    return ids
+
+
 def cpu_baseline(args, n_rays):
     """The oracle = CPU port arranged as the reference is (torch-CPU ATen ops + C/OpenMP restatement
-    of the 14 CUDA kernels), same workload shape, bounded ray count."""
+    of the 14 CUDA kernels), same workload shape, bounded ray count, SAME RAY ORDER as the GPU arm:
+    a run of n_rays consecutive rays of view 0 in the order the GPU arm walks it (starting at the
+    middle of the view), or random pixels when the GPU arm draws random pixels (--rays)."""
     from oracle import kernels as K
     from oracle import ref_render as R
 
@@ -270,9 +342,18 @@ def cpu_baseline(args, n_rays):
     if args.regime == "terminating":
         with torch.no_grad():
             ren.scene_field.mlp.bias[0] = 8.0
-    poses = fox_like_poses(args.n_images)
-    intr = torch.tensor([[1111.1, 0, args.width / 2], [0, 1111.1, args.height / 2], [0, 0, 1.0]])
-    pix = torch.randint(0, args.height * args.width, (n_rays,), generator=g)
+    poses = camera_poses(args)
+    intr = torch.tensor([[args.focal, 0, args.width / 2], [0, args.focal, args.height / 2], [0, 0, 1.0]])
+    if args.rays > 0:
+        pix = torch.randint(0, args.height * args.width, (n_rays,), generator=g)
+        order = "random pixels"
+    else:
+        ids = pixel_order(args.height, args.width, args.pixel_tiles if tiles_active(args) else 0)
+        lo = max(0, min(ids.numel() // 2, ids.numel() - n_rays))
+        pix = ids[lo:lo + n_rays]
+        n_rays = pix.numel()
+        order = "consecutive rays %d.. of view 0 in the GPU arm's order (%s)" % (
+            lo, "%dx%d tiles" % (args.pixel_tiles, args.pixel_tiles) if tiles_active(args) else "rows")
     ij = torch.stack([pix // args.width, pix % args.width], 1)
     o, d = R.get_rays_from_pose(poses[0:1], intr[None], ij)
     gt = torch.rand(n_rays, 3, generator=g)
@@ -296,31 +377,36 @@ def cpu_baseline(args, n_rays):
     med = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     return {"value": n_rays / med, "unit": "rays/s", "cores": cores, "kind": "port",
             "cpu_model": cpu_model(), "runs_s": [round(t, 4) for t in times],
-            "sample": "%d random rays of view 0, S=%d L=%d F=%d T=2^%d, fwd+bwd, median of %d timed "
+            "sample": "%d rays (%s), S=%d L=%d F=%d T=2^%d, fwd+bwd, median of %d timed "
                       "runs after %d warm-ups"
-                      % (n_rays, args.samples, args.levels, args.channels, args.log2_table,
+                      % (n_rays, order, args.samples, args.levels, args.channels, args.log2_table,
                          len(times), n_warm)}
 
 
 def dry_run(args, rank, world):
     """The multi-rank skeleton of main() with the GPU work left out: process group, per-rank shard,
-    the {sum sq err, n} all-reduce, max-over-ranks timing, one JSON line on rank 0."""
+    the {sum sq err, n} all-reduce (timed per step like the real run), max-over-ranks timing, one
+    JSON line on rank 0 carrying the same "collective" object as the real line."""
     pkg = importlib.import_module("f2-nerf_amd")
-    dist = None
+    dist, collective = (None, None)
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        dist, collective = init_collective(args, rank, world, "cpu")
     g = torch.Generator().manual_seed(2022)
     err = torch.rand(4099, 3, generator=g, dtype=torch.float64)
     lo, hi = pkg.sharding.shard_range(err.shape[0], rank, world)
     t0 = time.perf_counter()
-    stat = pkg.sharding.reduce_error_stats(err[lo:hi].square().sum(), err[lo:hi].numel(), dist)
+    us = []
+    for _ in range(max(args.steps, 1)):
+        t1 = time.perf_counter()
+        stat = pkg.sharding.reduce_error_stats(err[lo:hi].square().sum(), err[lo:hi].numel(), dist)
+        us.append((time.perf_counter() - t1) * 1e6)
     t_max = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        collective["allreduce_us"] = sorted(us)[len(us) // 2]
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "backend": args.backend if world > 1 else None,
+                          "collective": collective,
                           "views": [pkg.sharding.view_for(0, r, world, args.n_images) for r in range(world)],
                           "sq_err_sum": float(stat[0]), "n_values": float(stat[1]),
                           "want_sq_err_sum": float(err.square().sum()), "seconds": float(t_max)}),
@@ -332,8 +418,17 @@ def dry_run(args, rank, world):
 
 
 def run_c5(args, rank, world, dist, dev, pkg):
+    """--workload c5: the C5 measurement as its own JSON line."""
+    out = c5_measure(args, rank, world, dist, dev, pkg, args.steps, args.warmup,
+                     cpu_points=0 if (world > 1 or args.no_cpu_baseline) else 1 << 20)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def c5_measure(args, rank, world, dist, dev, pkg, steps, warmup, cpu_points):
     """BASELINE config C5: hash-grid encode forward + table-gradient backward through the C ABI,
-    inputs resident in HBM; one step = both kernels over the whole point set."""
+    inputs resident in HBM; one step = both kernels over the whole point set.  Returns the JSON
+    object on rank 0 (None elsewhere)."""
     capi = pkg.capi
     L, F, log2_T = 16, 8, 22
     T, C, n = 1 << log2_T, 16 * 8, args.c5_points
@@ -371,13 +466,13 @@ def run_c5(args, rank, world, dist, dev, pkg):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         fwd()
         bwd()
     barrier()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
     t0 = time.perf_counter()
-    for s_ in range(args.steps):
+    for s_ in range(steps):
         evs[s_][0].record()
         fwd()
         evs[s_][1].record()
@@ -389,10 +484,11 @@ def run_c5(args, rank, world, dist, dev, pkg):
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
+    del ws, enc, grad, tg, table16, pts
     if rank != 0:
-        return
-    ms_f = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps
-    ms_b = sum(e[1].elapsed_time(e[2]) for e in evs) / args.steps
+        return None
+    ms_f = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
+    ms_b = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
     b_f, b_b = algorithmic_bytes("hash_fwd", L, F, 0), algorithmic_bytes("hash_bwd", L, F, 0)
 
     def roof(op, ms, bytes_unit):
@@ -404,8 +500,8 @@ def run_c5(args, rank, world, dist, dev, pkg):
 
     out = {
         "metric": "hash-grid points/sec (encode fwd + table-gradient bwd), BASELINE config C5",
-        "value": n * args.steps * world / elapsed, "unit": "points/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "value": n * steps * world / elapsed, "unit": "points/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "C5: %d uniform points in the radius-2 ball, T=2^22 L=16 F=8, 1 GiB f16 table, "
@@ -418,19 +514,21 @@ def run_c5(args, rank, world, dist, dev, pkg):
                 "random-line rate of the memory system (profiles/r02_gather_policy_probe.txt), which caps "
                 "the algorithmic fraction at 16/128 of the line traffic",
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if cpu_points > 0:
         try:
-            out["cpu_baseline"] = cpu_baseline_c5(L, F, log2_T)
+            out["cpu_baseline"] = cpu_baseline_c5(L, F, log2_T, n=cpu_points,
+                                                  n_warm=2 if cpu_points >= 1 << 20 else 1,
+                                                  n_timed=5 if cpu_points >= 1 << 20 else 3)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         except Exception as e:
             out["cpu_baseline"] = {"value": None, "unit": "points/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": "failed: %r" % (e,)}
-    print(json.dumps(out), flush=True)
+    return out
 
 
-def cpu_baseline_c5(L, F, log2_T, n=1 << 20):
+def cpu_baseline_c5(L, F, log2_T, n=1 << 20, n_warm=2, n_timed=5):
     """The oracle's hash encode forward + backward (C/OpenMP restatement of the reference's two CUDA
-    kernels) on a bounded sample of config C5: same table size, 2^20 points."""
+    kernels) on a bounded sample of config C5: same table size, n points."""
     from oracle import kernels as K
 
     cores = int(os.environ.get("F2N_CPU_THREADS", "0")) or min(usable_cores(), 64)
@@ -447,17 +545,18 @@ def cpu_baseline_c5(L, F, log2_T, n=1 << 20):
     pts = (dd / dd.norm(dim=1, keepdim=True) * torch.rand(n, 1, generator=g) ** (1 / 3) * 2).contiguous()
     grad = torch.randn(n, L * F, generator=g) * 1e-3
     times = []
-    for it in range(2 + 5):
+    for it in range(n_warm + n_timed):
         t0 = time.perf_counter()
         K.hash_fwd(pts, table16, primes, bias, mul, L, F, T, T * F)
         K.hash_bwd(pts, table16, primes, bias, mul, grad, numel, L, F, T, T * F, 128.0, parallel=True)
-        if it >= 2:
+        if it >= n_warm:
             times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
     return {"value": n / med, "unit": "points/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "runs_s": [round(t, 4) for t in times],
-            "sample": "%d points of config C5 (same table), oracle hash fwd + bwd, median of 5 after 2 warm-ups" % n}
+            "sample": "%d points of config C5 (same table), oracle hash fwd + bwd, median of %d after %d "
+                      "warm-ups" % (n, n_timed, n_warm)}
 
 
 def time_train_iterations(args, pkg, H, dev, dist, world, poses, intr):
@@ -499,6 +598,97 @@ def time_train_iterations(args, pkg, H, dev, dist, world, poses, intr):
             "collectives_per_iteration": n_coll,
             "note": "reference batch shape (confs/train_config.yaml:4, points_sampler.hpp:15,39): "
                     "fwd + bwd + gradient all-reduce + fused Adam; not part of value"}
+
+
+def init_collective(args, rank, world, dev):
+    """Process group of the path's one collective.  world > 1: the launcher's ranks over --backend
+    ("nccl" IS RCCL on ROCm).  world == 1: a one-rank group over the same backend, so that the
+    driver's one-GPU record also shows the backend initialising and its all-reduce running on the
+    MI355X (a one-rank all-reduce moves nothing between GPUs; it is the same call path).  Returns
+    (torch.distributed or None, the "collective" object of the JSON line)."""
+    dev = torch.device(dev)
+    info = {"backend": None, "world_size": world, "allreduce_us": None,
+            "device_per_rank": ("%s (%s)" % (dev, torch.cuda.get_device_name(dev)) if dev.type == "cuda"
+                                else "cpu (dry run)"),
+            "payload": "2 x f64 {sum of squared error, value count}, all_reduce(SUM), once per step"}
+    if world == 1 and args.no_collective_at_1:
+        return None, info
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world == 1:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        probe = torch.ones(2, device=dev, dtype=torch.float64)
+        dist.all_reduce(probe)                       # communicator creation happens here, untimed
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        if float(probe[0]) != float(world):
+            raise RuntimeError("all_reduce(SUM) of ones over %d ranks gave %r" % (world, float(probe[0])))
+    except Exception as e:
+        if world > 1:
+            raise
+        info["error"] = "one-rank %s group not available: %r" % (args.backend, e)
+        return None, info
+    info["backend"] = dist.get_backend()
+    info["world_size"] = dist.get_world_size()          # what the backend saw, not what was asked for
+    if info["backend"] == "nccl":
+        try:
+            info["backend"] = "nccl (RCCL %s)" % ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            info["backend"] = "nccl (RCCL)"
+    return dist, info
+
+
+def time_hash_bwd_nonzero(args, pkg, H, ren, first_chunk, dev, reps=7):
+    """The table-gradient kernels (f2n_hash_bwd_binned) on the sample points of one chunk of the
+    headline workload -- same rays, same TRAIN jitter, same field -- with a gradient whose
+    contributions are ALL non-zero (tools/ab_hash_bwd.py's generator: N(0, 1e-3^2) per channel,
+    i.e. f16(128 g) w stays far above the f16 underflow), hipEvent-timed.  The headline's own
+    gradient comes from a mean loss over 65536 x 3 values of an untrained network and leaves ~90 %
+    of the contributions below the underflow, which the kernel skips (as zero-valued adds); a
+    512-ray training batch has gradients 128x larger.  This is that case, priced separately."""
+    capi = pkg.capi
+    o, d = first_chunk
+    S, L, F, T = args.samples, args.levels, args.channels, 1 << args.log2_table
+    field = ren.scene_field
+    sampler = ren.pts_sampler
+    pts = sampler.get_samples(o, d, "train")[0].reshape(-1, 3).contiguous()
+    n = pts.shape[0]
+    x = torch.empty_like(pts)
+    capi.call("contract_fwd", pts, x, n)
+    C = L * F
+    g = torch.Generator(device=dev).manual_seed(7)
+    grad = torch.randn(C, n, device=dev, generator=g) * 1e-3
+    tg = torch.zeros(field.feat_pool.numel(), device=dev)
+    need = capi.lib().cdll.f2n_hash_bwd_workspace_bytes(n, L, F, T)
+    if need <= 0:
+        return None
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    stride = field.level_stride
+
+    def run():
+        capi.call("hash_bwd_binned", x, field.prim_pool, field.bias_pool, field.level_mul, grad, 1, n, tg,
+                  n, L, F, T, stride, 128.0, ws, need)
+
+    run()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        run()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+    ms = ts[len(ts) // 2]
+    b = algorithmic_bytes("hash_bwd", L, F, S)
+    a = n * b / (ms * 1e-3) / 1e9
+    return {"launches": reps, "avg_ms": ms, "units_per_launch": n, "algorithmic_bytes_per_unit": b,
+            "achieved_GBs": a, "frac": a / HBM_PEAK_GBS,
+            "gradient": "N(0, 1e-3^2) per channel: every f16(128 g) w contribution non-zero",
+            "note": "same sample points as one %d-ray chunk of the headline; separately timed through "
+                    "the C ABI, median of %d launches; not part of value" % (o.shape[0], reps)}
 
 
 def _free_port():
@@ -547,11 +737,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+    dist, collective = init_collective(args, rank, world, dev)
 
     pkg = importlib.import_module("f2-nerf_amd")
     H = pkg.load_host()
@@ -559,7 +745,7 @@ def main():
         name, value = kv.split("=")
         pkg.capi.set_option(name, int(value))
     if args.workload == "c5":
-        run_c5(args, rank, world, dist, dev, pkg)
+        run_c5(args, rank, world, dist if world > 1 else None, dev, pkg)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -578,28 +764,31 @@ def main():
             params["scene_field.mlp.bias"][0] = 8.0
     torch.manual_seed(1000 + rank)   # per-rank randomness for noise / background from here on
 
-    poses = fox_like_poses(args.n_images).to(dev)
-    intr = torch.tensor([[1111.1, 0, args.width / 2], [0, 1111.1, args.height / 2], [0, 0, 1.0]],
+    poses = camera_poses(args).to(dev)
+    intr = torch.tensor([[args.focal, 0, args.width / 2], [0, args.focal, args.height / 2], [0, 0, 1.0]],
                         device=dev)
     n_rays_view = args.rays if args.rays > 0 else args.height * args.width
-    total_steps = args.warmup + args.steps
-    # inputs resident in HBM before timing: rays + ground truth of every view this rank renders
-    views = []
-    for s in range(total_steps):
-        v = pkg.sharding.view_for(s, rank, world, args.n_images)
-        o, d = view_rays(H, poses[v], intr, args.height, args.width)
-        if args.pixel_tiles > 1 and args.height % args.pixel_tiles == 0 and args.width % args.pixel_tiles == 0:
-            B, hh, ww = args.pixel_tiles, args.height, args.width
-            ids = torch.arange(hh * ww, device=dev).view(hh // B, B, ww // B, B).permute(0, 2, 1, 3).reshape(-1)
-            o, d = o[ids].contiguous(), d[ids].contiguous()
-        if args.rays > 0:
-            pick = torch.randint(0, o.shape[0], (args.rays,), device=dev)
-            o, d = o[pick].contiguous(), d[pick].contiguous()
-        gt = torch.rand(n_rays_view, 3, device=dev)
-        emb = torch.full((n_rays_view,), v, dtype=torch.int32, device=dev)
-        views.append((o, d, gt, emb))
 
-    def run_step(view):
+    def make_views(first_step, n_steps, tiles):
+        """Inputs resident in HBM before timing: rays + ground truth of every view this rank renders."""
+        views = []
+        for s in range(first_step, first_step + n_steps):
+            v = pkg.sharding.view_for(s, rank, world, args.n_images)
+            o, d = view_rays(H, poses[v], intr, args.height, args.width)
+            if tiles_active(args, tiles):
+                ids = pixel_order(args.height, args.width, tiles, dev)
+                o, d = o[ids].contiguous(), d[ids].contiguous()
+            if args.rays > 0:
+                pick = torch.randint(0, o.shape[0], (args.rays,), device=dev)
+                o, d = o[pick].contiguous(), d[pick].contiguous()
+            gt = torch.rand(n_rays_view, 3, device=dev)
+            emb = torch.full((n_rays_view,), v, dtype=torch.int32, device=dev)
+            views.append((o, d, gt, emb))
+        return views
+
+    reduce_events = []
+
+    def run_step(view, timed=False):
         o, d, gt, emb = view
         ren.zero_grad()
         sq = torch.zeros((), device=dev, dtype=torch.float64)
@@ -612,7 +801,14 @@ def main():
             n_val += nv
             n_samples += ns
         # the only collective of the path: {sum sq err, count} -> global PSNR (RCCL all-reduce)
-        stat = pkg.sharding.reduce_error_stats(sq, n_val, dist)
+        if timed and dist is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            stat = pkg.sharding.reduce_error_stats(sq, n_val, dist)
+            e1.record()
+            reduce_events.append((e0, e1))
+        else:
+            stat = pkg.sharding.reduce_error_stats(sq, n_val, dist)
         return stat, n_samples
 
     def barrier():
@@ -620,28 +816,65 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        run_step(views[s])
-    barrier()
+    def timed_leg(views, n_warm):
+        """n_warm untimed steps, then the rest timed between barrier + synchronize on both sides;
+        returns (elapsed seconds = max over ranks, samples, last error statistics, kernel timings)."""
+        for s in range(n_warm):
+            run_step(views[s])
+        barrier()
+        H.kernel_timer_enable(True)
+        H.kernel_timer_collect()
+        t0 = time.perf_counter()
+        n_samples_total = 0
+        stat = None
+        for s in range(n_warm, len(views)):
+            stat, ns = run_step(views[s], timed=True)
+            n_samples_total += ns
+        barrier()
+        elapsed = time.perf_counter() - t0
+        H.kernel_timer_enable(False)
+        timings = H.kernel_timer_collect()
+        t_max = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return float(t_max.item()), n_samples_total, stat, timings
+
+    views = make_views(0, args.warmup + args.steps, args.pixel_tiles)
     bin_counters = None
     if args.debug_bin_stats and rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bin_stats
         bin_counters = bin_stats.enable(pkg.capi.lib().cdll, dev)
-    H.kernel_timer_enable(True)
-    H.kernel_timer_collect()
-    t0 = time.perf_counter()
-    n_samples_total = 0
-    stat = None
-    for s in range(args.warmup, total_steps):
-        stat, ns = run_step(views[s])
-        n_samples_total += ns
-    barrier()
-    elapsed = time.perf_counter() - t0
-    H.kernel_timer_enable(False)
-    timings = H.kernel_timer_collect()
+    elapsed, n_samples_total, stat, timings = timed_leg(views, args.warmup)
     if bin_counters is not None:
         bin_stats.report(pkg.capi.lib().cdll, bin_counters, L, out=sys.stderr)
+    if reduce_events:
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in reduce_events)
+        collective["allreduce_us"] = us[len(us) // 2]
+        collective["allreduce_us_all"] = [round(u, 1) for u in us[:64]]
+    reduce_events.clear()
+    first_chunk = tuple(t[:args.chunk] for t in views[-1][:2])
+    del views
+
+    # ---- extras: separately timed, never part of value ---------------------------------------------
+    extras = {}
+    want_extras = not args.no_extras and args.workload in ("render", "c2") and args.rays == 0
+    if want_extras and tiles_active(args, 8) and args.pixel_tiles != 8:
+        # the same views handed over in 8x8 pixel tiles (the Renderer's own traversal in render_image)
+        n_w, n_t = min(args.warmup, 2), min(args.steps, 5)
+        tv = make_views(0, n_w + n_t, 8)
+        t_el, _, _, t_tim = timed_leg(tv, n_w)
+        del tv
+        extras["pixel_tiles_8x8"] = {
+            "value": n_rays_view * n_t * world / t_el, "unit": "rays/s", "steps": n_t, "warmup": n_w,
+            "ms_per_step": t_el / n_t * 1e3,
+            "hash_fwd_avg_ms": (t_tim["hash_fwd"][1] / max(t_tim["hash_fwd"][0], 1)) if "hash_fwd" in t_tim else None,
+            "note": "same rays, same chunks, handed over in 8x8 pixel tiles instead of rows (round 2's "
+                    "headline order); not part of value"}
+        reduce_events.clear()
+    nonzero = None
+    if want_extras and rank == 0:
+        nonzero = time_hash_bwd_nonzero(args, pkg, H, ren, first_chunk, dev)
 
     # optimiser step: outside the headline (BASELINE.md excludes it) but reported next to it
     opt_ms = {}
@@ -672,13 +905,22 @@ def main():
                               "not part of value" % (args.height, args.width, S)}
     train_iter = None
     if args.train_iters > 0:
-        train_iter = time_train_iterations(args, pkg, H, dev, dist, world, poses, intr)
+        train_iter = time_train_iterations(args, pkg, H, dev, dist if world > 1 else None, world, poses, intr)
 
-    t_max = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
     psnr, mse = pkg.sharding.psnr_from_stats(stat)   # reference train_manager.cpp:96
+    c5 = None
+    if want_extras and world == 1:
+        # BASELINE config C5 (the HBM stress) once after the headline, so that the driver's record
+        # carries it: the hash kernels alone, bounded CPU leg
+        del ren, params
+        torch.cuda.empty_cache()
+        try:
+            full = c5_measure(args, rank, world, None, dev, pkg, steps=2, warmup=1,
+                              cpu_points=0 if args.no_cpu_baseline else 1 << 18)
+            c5 = {k: full[k] for k in ("value", "unit", "ms_per_step", "roofline", "roofline_fwd",
+                                       "cpu_baseline", "gpu_over_cpu", "config") if k in full}
+        except Exception as e:  # an extra: never a reason to lose the line
+            c5 = {"error": repr(e)}
 
     if rank == 0:
         rays_total = n_rays_view * args.steps * world
@@ -700,44 +942,60 @@ def main():
                 kernels[name].update({
                     "algorithmic_bytes_per_unit": b,
                     "achieved_GBs": (units * b) / (total_ms * 1e-3) / 1e9 if total_ms > 0 else None})
+
+        def roofline_of(op):
+            if op not in kernels or not kernels[op].get("achieved_GBs"):
+                return None
+            a = kernels[op]["achieved_GBs"]
+            traffic, traffic_src = pmc_traffic(op, workload_key(args))
+            return {"kernel": op, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": kernels[op]["units_per_launch"] *
+                    kernels[op]["algorithmic_bytes_per_unit"],
+                    "avg_launch_ms": kernels[op]["avg_ms"]}
+
         hbm = [k for k in kernels if "achieved_GBs" in kernels[k]]
         dom = max(hbm, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"]) if hbm else None
-        roofline = None
-        if dom:
-            a = kernels[dom]["achieved_GBs"]
-            traffic, traffic_src = pmc_traffic(dom, workload_key(args))
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": traffic,
-                        "traffic_source": traffic_src,
-                        "algorithmic_bytes_per_launch": kernels[dom]["units_per_launch"] *
-                        kernels[dom]["algorithmic_bytes_per_unit"],
-                        "avg_launch_ms": kernels[dom]["avg_ms"]}
+        if nonzero is not None:
+            kernels["hash_bwd_nonzero"] = nonzero
+        tiles_on = tiles_active(args)
+        if args.workload == "c3":
+            what = ("C3: free-trajectory views %dx%d (120-pose 3-turn expanding spiral, look-ahead "
+                    "orientation, fx=fy=%g), " % (args.height, args.width, args.focal))
+        elif args.rays > 0:
+            what = ("%s%d random rays per step per GPU, " %
+                    ("C4 per-GPU shape (the reference's own batch): " if args.rays == 512 and S == 1024 else "",
+                     args.rays))
+        else:
+            what = "ngp_fox-like synthetic views %dx%d, " % (args.height, args.width)
         out = {
             "metric": "rendered rays/sec (fwd+bwd) at 800x800",
             "value": rays_total / elapsed, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": ("ngp_fox-like synthetic views %dx%d, " % (args.height, args.width) if
-                                    args.rays == 0 else "%d random rays per step, " % args.rays) +
-                                   "%d samples/ray, L=%d F=%d T=2^%d, %d-ray chunks, TRAIN render + "
-                                   "loss + backward (optimizer excluded)"
+            "config": {"workload": what + "%d samples/ray, L=%d F=%d T=2^%d, %d-ray chunks, TRAIN render + "
+                                          "loss + backward (optimizer excluded)"
                                    % (S, L, F, args.log2_table, args.chunk),
-                       "pixel_order": ("%dx%d tiles" % (args.pixel_tiles, args.pixel_tiles)
-                                       if args.rays == 0 and args.pixel_tiles > 1 and
-                                       args.height % args.pixel_tiles == 0 and args.width % args.pixel_tiles == 0
+                       "pixel_order": ("%dx%d tiles" % (args.pixel_tiles, args.pixel_tiles) if tiles_on
                                        else ("rows" if args.rays == 0 else "random")),
                        "regime": args.regime, "rays_per_step_per_gpu": n_rays_view,
                        "samples_per_ray_kept": n_samples_total / (n_rays_view * args.steps),
                        "sharding": "one view per rank per step, RCCL all-reduce of {sq_err, n} only"},
             "kernel_options": args.option,
             "psnr_vs_random_gt": psnr,
+            "collective": collective,
             "optimizer_step_ms": {"fused_adam_with_f16_shadow": opt_ms["make_fused_adam"],
                                   "torch_optim_adam": opt_ms["make_adam"],
                                   "note": "per call, not part of value (BASELINE.md section 2)"},
-            "roofline": roofline,
+            "roofline": roofline_of(dom) if dom else None,
+            "hash_fwd_roofline": roofline_of("hash_fwd"),
             "kernels": kernels,
         }
+        out.update(extras)
+        if c5 is not None:
+            out["c5"] = c5
         if train_iter is not None:
             out["train_iteration"] = train_iter
         if render_img is not None:

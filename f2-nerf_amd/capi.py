@@ -60,7 +60,7 @@ class _Lib:
             fn = getattr(self.cdll, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = ret
             fn.argtypes = [t for t, _ in params]
-        if self.cdll.f2n_abi_version() != 1:
+        if self.cdll.f2n_abi_version() != 2:
             raise F2NError("ABI version mismatch")
 
     def status_string(self, st):

@@ -7,6 +7,7 @@
 
 #include <cmath>
 
+#include <c10/hip/HIPGuard.h>
 #include <hip/hip_runtime_api.h>
 
 using Tensor = torch::Tensor;
@@ -298,13 +299,14 @@ variable_list Hash3DAnchoredFunction::backward(AutogradContext * ctx, variable_l
   // Large training batches: bin the contributions by table slice into a scratch workspace and
   // reduce them in LDS (no scattered atomics; exact, order-independent sums).  The recommended
   // workspace is about 3 bytes per algorithmic byte (16 GiB for 8.4 M samples at L = 16, F = 2,
-  // capped at 24 GiB: bigger batches run in rounds); it is further capped at half of the device's
+  // capped at 48 GiB: bigger batches run in rounds); it is further capped at half of the device's
   // free memory, and when even that cannot be allocated the atomic kernel takes over.
   int64_t ws_bytes =
     want_points ? 0 : f2n_hash_bwd_workspace_bytes(n, L, F, (uint32_t)field->local_size_);
   Tensor ws;
   if (ws_bytes > 0 && field->options_.binned_backward) {
     size_t free_b = 0, total_b = 0;
+    c10::hip::HIPGuard on_device(points.device().index());  // the query is about THIS tensor's device
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       // memory held by the caching allocator is reusable too: only cap when the device is tight
       const int64_t cap = (int64_t)(free_b / 2);

@@ -22,14 +22,24 @@ void f2n::HostCount::request(const torch::Tensor & device_int32, void * stream)
   TORCH_CHECK(
     device_int32.is_cuda() && device_int32.scalar_type() == torch::kInt32 && device_int32.numel() == 1,
     "HostCount: one int32 on the device");
-  c10::hip::HIPGuard on_device(device_int32.device().index());
-  if (!pinned_) {
+  const int device = (int)device_int32.device().index();
+  c10::hip::HIPGuard on_device(device);
+  if (pending_) {  // a read nobody waited for (an exception between request and wait): drain it
+    hipEventSynchronize((hipEvent_t)event_);
+    pending_ = false;
+  }
+  if (!pinned_)
     TORCH_CHECK(hipHostMalloc((void **)&pinned_, sizeof(int32_t), hipHostMallocDefault) == hipSuccess,
                 "HostCount: pinned allocation failed");
+  if (!event_ || device_ != device) {
+    // an event belongs to the device it was created on: a Renderer whose inputs moved to another
+    // GPU gets a new one (the pinned word is host memory and stays)
+    if (event_) hipEventDestroy((hipEvent_t)event_);
     hipEvent_t ev;
     TORCH_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess,
                 "HostCount: event creation failed");
     event_ = ev;
+    device_ = device;
   }
   TORCH_CHECK(
     hipMemcpyAsync(pinned_, device_int32.data_ptr<int32_t>(), sizeof(int32_t), hipMemcpyDeviceToHost,

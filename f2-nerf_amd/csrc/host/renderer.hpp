@@ -39,6 +39,7 @@ public:
 private:
   int32_t * pinned_ = nullptr;
   void * event_ = nullptr;
+  int device_ = -1;  // device the event belongs to (recreated when a request comes from another one)
   bool pending_ = false;
 };
 }  // namespace f2n

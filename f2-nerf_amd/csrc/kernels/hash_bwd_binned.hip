@@ -210,6 +210,7 @@ struct BinArgs
   float grad_scale, inv_scale;
   int n_buckets, bshift, groups, qcap, qcap_comb, combine;
   uint32_t * stats;  // optional [L][4] u32 counters (tools/ab_hash_bwd.py), else NULL
+  unsigned long long * overflow;  // optional: += records applied with float atomics, else NULL
 };
 
 // SAT: sum the saturated cell (0,0,0) in LDS (tables that take the split pass); a template
@@ -374,8 +375,10 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       if (slot < (uint32_t)cap)
         // (bucket < 64, cap * KW <= 32768: a 24-bit multiply is full rate, v_mul_lo_u32 a quarter)
         store_record<F>(queue + __umul24(bucket, (uint32_t)(cap * KW)), cap, slot, r & bmask, val);
-      else
+      else {
         apply_record_atomic<F>(gbase, r, val, a.inv_scale);
+        if (a.overflow) atomicAdd(a.overflow, 1ull);
+      }
     };
     // wave w copies the queues of buckets w, w+16, ... to their workspace regions and records the
     // counts ([level][bucket][tile] so that pass B / C read them coalesced)
@@ -550,6 +553,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
           enqueue(r, val, a.qcap_comb);
         }
         if (nz) {  // sums beyond kMaxPieces * 11 bits (near the f16 overflow): the rest goes direct
+          if (a.overflow) atomicAdd(a.overflow, 1ull);
 #pragma unroll
           for (int k = 0; k < F; k++)
             if (S[k] != 0)
@@ -659,6 +663,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
                 enqueue(r, val, a.qcap);
               }
               if (nz) {
+                if (a.overflow) atomicAdd(a.overflow, 1ull);
 #pragma unroll
                 for (int k = 0; k < F; k++)
                   if (S[k] != 0)
@@ -692,6 +697,7 @@ struct SplitArgs
   float inv_scale;
   int n_buckets, bshift, log2_sub, qcap, n_slices, tiles_per_part, n_parts, cap2;
   uint32_t * stats;  // optional [L][4] counters: [3] += records that overflowed a queue or a run
+  unsigned long long * overflow;  // optional: += records applied with float atomics, else NULL
 };
 
 template <int F>
@@ -750,6 +756,7 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
           } else {
             apply_record_atomic<F>(gbase, row0 + r[u], v[u], a.inv_scale);
             if (a.stats) atomicAdd(a.stats + 4 * l + 3, 1u);
+            if (a.overflow) atomicAdd(a.overflow, 1ull);
           }
         }
       }
@@ -768,6 +775,7 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
           load_record<F>(queue + (size_t)sub * Q * KW, Q, i, rr, vv);
           apply_record_atomic<F>(gbase, row0 + (uint32_t)sub * kRows + rr, vv, a.inv_scale);
           if (a.stats) atomicAdd(a.stats + 4 * l + 2, 1u);
+          if (a.overflow) atomicAdd(a.overflow, 1ull);
         }
       }
       if (lane == 0) {
@@ -1107,6 +1115,7 @@ BinPlan bin_plan(int64_t n, int L, int F, uint32_t T, int64_t workspace_bytes)
 constexpr int64_t kRecommendedWorkspaceCap = (int64_t)48 << 30;
 
 std::atomic<uint32_t *> g_bin_stats{nullptr};
+std::atomic<unsigned long long *> g_overflow_counter{nullptr};
 
 inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1u)); }
 
@@ -1118,6 +1127,14 @@ inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1u)); }
 extern "C" void f2n_debug_bin_stats(uint32_t * device_counters)
 {
   g_bin_stats.store(device_counters, std::memory_order_relaxed);
+}
+
+extern "C" int f2n_hash_bwd_set_overflow_counter(uint64_t * device_counter)
+{
+  if (reinterpret_cast<uintptr_t>(device_counter) & 7u) return F2N_E_INVALID_ARG;
+  g_overflow_counter.store(
+    reinterpret_cast<unsigned long long *>(device_counter), std::memory_order_relaxed);
+  return F2N_OK;
 }
 
 extern "C" int64_t f2n_hash_bwd_workspace_bytes(int64_t n, int L, int F, uint32_t T)
@@ -1193,6 +1210,7 @@ extern "C" int f2n_hash_bwd_binned(
     ba.qcap_comb = pl.qcap_comb;
     ba.combine = combine;
     ba.stats = g_bin_stats.load(std::memory_order_relaxed);
+    ba.overflow = g_overflow_counter.load(std::memory_order_relaxed);
     const int64_t tiles_g = tiles * pl.groups;
 #define F2N_BIN_LAUNCH(P2, SAT)                                                                     \
   hipLaunchKernelGGL(                                                                              \
@@ -1236,6 +1254,7 @@ extern "C" int f2n_hash_bwd_binned(
         sa.n_parts = pl.n_parts;
         sa.cap2 = pl.cap2;
         sa.stats = g_bin_stats.load(std::memory_order_relaxed);
+        sa.overflow = ba.overflow;
         const dim3 grid_b((unsigned)pl.n_buckets, (unsigned)L, (unsigned)pl.n_parts);
         hipLaunchKernelGGL((hash_bwd_split_kernel<FF>), grid_b, dim3(kSplitBlock), 0, s, sa);
         const dim3 grid_c((unsigned)pl.n_slices, (unsigned)L);

@@ -33,7 +33,9 @@ def reduce_error_stats(sq_err_sum, n_values, dist=None, group=None):
     dev = sq_err_sum.device if torch.is_tensor(sq_err_sum) else "cpu"
     stat = torch.stack([torch.as_tensor(sq_err_sum, dtype=torch.float64, device=dev).reshape(()),
                         torch.tensor(float(n_values), dtype=torch.float64, device=dev)])
-    if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+    # (also with a single rank: a one-rank group still runs the backend's collective, which is how
+    # bench.py --gpus 1 exercises RCCL on a one-GPU box)
+    if dist is not None and dist.is_initialized():
         dist.all_reduce(stat, group=group)
     return stat
 

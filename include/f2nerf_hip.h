@@ -27,7 +27,10 @@
 extern "C" {
 #endif
 
-#define F2N_ABI_VERSION 1
+/* 2: f2n_set_option / f2n_get_option (explicit process-wide route table; nothing is read from the
+ *    environment any more), f2n_density_margin, f2n_hash_bwd_set_overflow_counter; f2n_hash_bwd_binned
+ *    returns F2N_E_UNSUPPORTED for a workspace that cannot hold one tile and applies to n >= 65536. */
+#define F2N_ABI_VERSION 2
 
 #define F2N_OK 0
 #define F2N_E_INVALID_ARG (-1) /* null pointer, negative count, unsupported L/F/degree ...     */
@@ -104,16 +107,27 @@ int f2n_hash_bwd(
 /* Same operation as f2n_hash_bwd without the point gradient, for large batches: contributions are
  * binned by table slice into a caller-provided workspace and summed EXACTLY (64-bit fixed point) in
  * LDS, so the scattered f16/f32 atomics of Hash3DAnchoredBackwardKernel
- * (src/hash_3d_anchored.cu:129-137) disappear and the result does not depend on summation order.
+ * (src/hash_3d_anchored.cu:129-137) disappear and the result does not depend on summation order --
+ * with one condition: a record that finds an LDS queue, a workspace region or a run full, or that
+ * holds a non-finite half, is applied directly with a global float atomic, and where two such
+ * records meet on one element the last bits depend on their order (as the reference's own atomics
+ * do everywhere).  f2n_hash_bwd_set_overflow_counter() makes the passes count those records.
  * Tables with more than 64 LDS-sized slices per level (T*F > 2^20, e.g. T = 2^22, F = 8) take a
  * second binning pass; coarse levels whose cells are shared by the points of a tile are combined
  * before they are binned (F2N_OPT_BWD_COMBINE).
- * f2n_hash_bwd_workspace_bytes returns the recommended workspace size (at most 24 GiB), or 0 when
+ * f2n_hash_bwd_workspace_bytes returns the recommended workspace size (at most 48 GiB), or 0 when
  * the binned path does not apply to (n, L, F, T): n < 65536 or T*F > 2^26 -- use f2n_hash_bwd then.
  * workspace: device memory, 256-byte aligned, contents undefined on entry and exit.  A smaller
  * workspace makes the passes run in several rounds over the points (same results);
  * F2N_E_UNSUPPORTED when it cannot hold one 1024-point tile. */
 int64_t f2n_hash_bwd_workspace_bytes(int64_t n, int L, int F, uint32_t T);
+/* Overflow accounting of f2n_hash_bwd_binned (process-wide, like f2n_set_option): a caller-owned
+ * device word (8-byte aligned) that every later call increments once per record it applied with a
+ * global float atomic instead of the exact sum (a full queue / region / run, a combined sum beyond
+ * the f16 range) -- 0 afterwards means the result is independent of summation order, bit for bit.
+ * NULL (the default) switches the counting off.  The reference's kernel has no such distinction:
+ * every one of its adds is an order-dependent atomic (src/hash_3d_anchored.cu:129-137). */
+int f2n_hash_bwd_set_overflow_counter(uint64_t * device_counter);
 int f2n_hash_bwd_binned(
   const float * pts, const int32_t * primes, const float * bias, const float * mul,
   const float * grad_out, int64_t g_ld_point, int64_t g_ld_chan, float * table_grad, int64_t n,

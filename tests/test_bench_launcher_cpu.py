@@ -38,6 +38,11 @@ def test_self_launch_two_ranks_gloo():
     assert len(lines) == 1, res.stdout            # rank 0 only
     d = lines[0]
     assert d["n_gpus"] == 2 and d["views"] == [0, 1]
+    # a SCALE record proves itself: what the backend saw, not what the flags asked for
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2
+    assert c["allreduce_us"] is not None and c["allreduce_us"] > 0
+    assert "device_per_rank" in c and "payload" in c
     assert d["n_values"] == 4099 * 3
     assert abs(d["sq_err_sum"] - d["want_sq_err_sum"]) <= 1e-9 * d["want_sq_err_sum"]
 
@@ -50,6 +55,41 @@ def test_under_external_launcher():
     assert res.returncode == 0, res.stderr[-2000:]
     lines = _json_lines(res.stdout)
     assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+    assert lines[0]["collective"]["world_size"] == 2 and lines[0]["collective"]["backend"] == "gloo"
+
+
+def test_presets_name_the_baseline_configs():
+    """--workload c3 / c4 fill in BASELINE.md's shapes; explicit flags win over a preset."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py", "--workload", "c3"]
+        a = bench.parse_args()
+        assert (a.height, a.width, a.samples, a.n_images, a.focal) == (1080, 1920, 192, 120, 1400.0)
+        poses = bench.camera_poses(a)
+        assert poses.shape == (120, 3, 4)
+        # normalised as dataset.cpp:77-86: the farthest camera sits at distance 1 from the mean position
+        assert abs(float(poses[:, :, 3].norm(dim=1).max()) - 1.0) < 1e-5
+        R = poses[:, :, :3]
+        eye = R.transpose(1, 2) @ R
+        assert float((eye - bench.torch.eye(3)).abs().max()) < 1e-5      # orthonormal camera frames
+        # look-ahead: -z (forward) points along the direction of travel
+        travel = poses[1:, :, 3] - poses[:-1, :, 3]
+        fwd = -poses[:-1, :, 2]
+        cos = (travel * fwd).sum(1) / travel.norm(dim=1)
+        assert float(cos.min()) > 0.9
+        sys.argv = ["bench.py", "--workload", "c4"]
+        a = bench.parse_args()
+        assert (a.rays, a.samples) == (512, 1024)
+        sys.argv = ["bench.py", "--workload", "c3", "--samples", "64"]
+        assert bench.parse_args().samples == 64
+        sys.argv = ["bench.py"]
+        a = bench.parse_args()
+        assert a.pixel_tiles == 0 and bench.workload_key(a) == "c2"      # rows: the comparable headline
+    finally:
+        sys.argv = argv
 
 
 def test_world_size_mismatch_is_an_error():

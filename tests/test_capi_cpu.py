@@ -24,7 +24,7 @@ def test_header_symbols_all_exported(capi):
     for name in decls:
         assert hasattr(cdll, name), name
     lib = capi.lib()
-    assert lib.cdll.f2n_abi_version() == 1
+    assert lib.cdll.f2n_abi_version() == 2
     assert lib.status_string(0) == "ok" and "invalid" in lib.status_string(-1)
 
 

@@ -212,7 +212,10 @@ def test_config_c5_full_batch_properties(capi, dev, field_c5):
     """2^22 points of config C5 (a quarter of its batch; 8.6 GB of encodings for the full 2^24 would
     only repeat this): the binned backward runs in several rounds over the points inside a 20 GiB
     workspace and must (a) agree with the scattered-atomic kernel, (b) conserve the gradient
-    (sum_d w_d = 1), (c) be bitwise reproducible (exact fixed-point sums)."""
+    (sum_d w_d = 1), (c) be bitwise reproducible (exact fixed-point sums) whenever the overflow
+    counter of f2n_hash_bwd_set_overflow_counter reads 0 -- records that found a queue or run full
+    are applied with float atomics and may differ in the last bits where two of them meet; their
+    number is bounded here and the affected entries stay within f16 resolution of each other."""
     f = field_c5
     L5, F5, T5 = C5["L"], C5["F"], 1 << C5["LOG2T"]
     st = T5 * F5
@@ -224,19 +227,30 @@ def test_config_c5_full_batch_properties(capi, dev, field_c5):
     assert 0 < need <= (48 << 30) + 4096
     need = min(need, 20 << 30)          # less than one round's worth: at least two rounds
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int64, device=dev)
+    assert capi.lib().cdll.f2n_hash_bwd_set_overflow_counter(overflow.data_ptr()) == 0
     outs = []
-    for _ in range(2):
-        tg = torch.zeros(f["numel"], device=dev)
-        capi.call("hash_bwd_binned", x, f["primes"], f["bias"], f["mul"], g, 1, n, tg, n, L5, F5, T5,
-                  st, 128.0, ws, need)
-        outs.append(tg)
+    try:
+        for _ in range(2):
+            tg = torch.zeros(f["numel"], device=dev)
+            capi.call("hash_bwd_binned", x, f["primes"], f["bias"], f["mul"], g, 1, n, tg, n, L5, F5, T5,
+                      st, 128.0, ws, need)
+            outs.append(tg)
+        torch.cuda.synchronize()
+    finally:
+        capi.lib().cdll.f2n_hash_bwd_set_overflow_counter(None)
     del ws
-    # exact sums except where a queue or run overflowed into float atomics (coarse levels: uniformly
-    # random points hit only ~36 000 distinct rows of level 0, so some slices see several times the
-    # mean record count); those entries are order-dependent in their last bits
+    n_over = int(overflow.item())
     scale = float(outs[0].abs().max())
-    assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
-    assert float((outs[0] != outs[1]).float().mean()) < 0.01
+    if n_over == 0:
+        assert torch.equal(outs[0], outs[1])          # exact sums: independent of summation order
+    else:
+        # records that overflowed into float atomics (coarse levels: uniformly random points hit only
+        # ~36 000 distinct rows of level 0, so some slices see several times the mean record count):
+        # few, and the entries they touch are order-dependent in their last bits only
+        assert n_over < 0.01 * 2 * n * L5 * 8, n_over
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
+        assert float((outs[0] != outs[1]).float().mean()) < 0.01
     with capi.option("HASH_BWD", 1):
         ta = torch.zeros(f["numel"], device=dev)
         capi.call("hash_bwd", x, f["table16"], f["primes"], f["bias"], f["mul"], g, 1, n, ta, None, n,

@@ -52,12 +52,14 @@ def _close(a, b, rtol, atol_frac=1e-5):
 
 
 def _close_samples(a, b):
-    """Per-sample weights.  The reference forms t by a device cumsum of 1024 f32 steps (a parallel
-    scan; the oracle and the HIP sampler add sequentially), so sample positions differ by a few 1e-6
-    and a random-valued table turns that into ~1e-3 relative differences of individual densities, a
-    few times that in the tail -- in all three pairings (measured: reference / oracle / this
-    Renderer differ pairwise by the same amount).  Integrated quantities (colours, depths, loss) are
-    held to 1e-4; individual weights to 1e-4 in the median and 2e-3 in relative L2."""
+    """Per-sample weights of two parties whose sample POSITIONS differ.  The reference forms t by a
+    device cumsum of 1024 f32 steps (a parallel scan; the oracle and the HIP sampler add
+    sequentially), so positions differ by a few 1e-6 (bounded where this is used) and a
+    random-valued table turns that into ~1e-3 relative differences of individual densities, a few
+    times that in the tail.  That this one op is the cause is shown in the dense leg below: with the
+    oracle's cumsum run where the reference runs it, per-sample weights agree to 1e-4.  Integrated
+    quantities (colours, depths, loss) are held to 1e-4 either way; individual weights at differing
+    positions to 1e-4 in the median and 2e-3 in relative L2."""
     rel = (a - b).abs() / b.abs().clamp_min(1e-12)
     assert float(rel.median()) < 1e-4, float(rel.median())
     assert float((a - b).norm() / b.norm()) < 2e-3
@@ -119,6 +121,23 @@ def test_reference_renderer_train_matches_oracle_and_this_renderer(host, dev, tm
     _close(ref["colors"], res.colors.detach(), 1e-4)
     _close(ref["depths"], res.depths.detach(), 1e-4)
     _close_samples(ref["weights"], res.weights.detach())
+    # ... and with IDENTICAL positions: the oracle's t formed by the same device cumsum the reference
+    # calls (src/points_sampler.cpp:38) -- per-sample weights at the north star's 1e-4
+    oracle.cumsum_device = dev
+    with torch.no_grad():
+        res_same = oracle.render(o, d, emb, R.TRAIN, noise.cpu(), bg.cpu())
+    oracle.cumsum_device = None
+    assert torch.equal(ref["idx_start_end"], res_same.idx_start_end)
+    _close(ref["weights"], res_same.weights, 1e-4)
+    _close(ref["colors"], res_same.colors, 1e-4)
+    # how far apart the positions of the three parties are: t of the reference (device cumsum),
+    # of the oracle (sequential) and of the HIP sampler (wave scan)
+    t_ref = (torch.cumsum(noise, 1) * (1.0 / 256)).cpu()
+    t_seq = torch.cumsum(noise.cpu(), 1) * (1.0 / 256)
+    t_hip = host.PtsSampler(S, 1.0 / 256).get_samples(o.to(dev), d.to(dev), "train", noise)[3].cpu().view(n_rays, S)
+    for t_other in (t_seq, t_hip):
+        rel = ((t_other - t_ref).abs() / t_ref).max().item()
+        assert 0.0 < rel <= 2e-6, rel          # they DO differ, by a few f32 ulps of t
     assert abs(ref["loss"] - float(loss)) <= 1e-5 * abs(float(loss))
     assert abs(ref["mse"] - mse) <= 1e-5 * mse
     for k, want in _oracle_grads(oracle).items():
