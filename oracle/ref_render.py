@@ -209,35 +209,39 @@ class SHShader(torch.nn.Module):
         return (1.0 + 2.0 * eps) / (1.0 + torch.exp(-out)) - eps
 
 
-def get_samples(rays_o_raw, rays_d_raw, noise, S=1024, step=1.0 / 256, cumsum_device=None):
+def get_samples(rays_o_raw, rays_d_raw, noise, S=1024, step=1.0 / 256, sampler_device=None):
     """PtsSampler::get_samples, src/points_sampler.cpp:20-64.  `noise` [n_rays, S] replaces the
     device torch::rand of :35 (TRAIN: U[0,1)-0.5+1); None = VALIDATE (ones, :33).
 
-    cumsum_device: where torch.cumsum of :38 runs.  None = here on the CPU (a sequential f32 sum).
-    The reference calls the same ATen op on its device, where it is a parallel scan that associates
-    the 1024 additions differently: t differs by a few ulps, the positions by a few 1e-6.  Passing
-    the GPU reproduces the reference's t bit for bit (tests/test_gpu_ref_host.py uses this to show
-    that the per-sample differences between the reference and this oracle come from that one op)."""
-    rays_o = rays_o_raw.contiguous()
+    sampler_device: where these ATen ops run.  None = on the CPU, like the rest of this oracle.  The
+    reference runs the very same ops on its device, where linalg_norm and cumsum (a parallel scan)
+    associate differently: d^ and t differ by an ulp or a few, the positions by a few 1e-7..1e-6 --
+    and because dt is the norm of the DIFFERENCE of neighbouring positions (quirk Q7: 0.004 formed
+    from two numbers near 1..4) that re-draws the rounding of dt at the 1e-4..1e-3 relative level.
+    Passing the GPU reproduces the reference's samples bit for bit (same ops, same torch build);
+    tests/test_gpu_ref_host.py uses it to show that the per-sample differences between the reference
+    and this oracle come from the sampler's op placement and from nothing downstream."""
+    out_dev = rays_o_raw.device
+    dev = out_dev if sampler_device is None else torch.device(sampler_device)
+    rays_o = rays_o_raw.to(dev).contiguous()
+    rays_d_raw = rays_d_raw.to(dev)
     rays_d = (rays_d_raw / torch.linalg.norm(rays_d_raw, 2, -1, True)).contiguous()
     n_rays = rays_o.shape[0]
     n_all = n_rays * S
-    rays_noise = torch.ones(n_rays, S) if noise is None else noise.reshape(n_rays, S)
-    if cumsum_device is None:
-        cum_noise = torch.cumsum(rays_noise, 1) * step
-    else:
-        cum_noise = torch.cumsum(rays_noise.to(cumsum_device), 1).to(rays_noise.device) * step
+    rays_noise = torch.ones(n_rays, S, device=dev) if noise is None else noise.to(dev).reshape(n_rays, S)
+    cum_noise = torch.cumsum(rays_noise, 1) * step
     sampled_t = cum_noise.reshape(n_all).contiguous()
     o = rays_o.view(n_rays, 1, 3)
     d = rays_d.view(n_rays, 1, 3)
     sampled_pts = o + d * cum_noise.unsqueeze(-1)
     dist = torch.diff(sampled_pts, 1, 1).norm(2, -1)
-    dist = torch.cat([torch.zeros(n_rays, 1), dist], 1).contiguous()
-    num = torch.full((n_rays,), S, dtype=torch.int32)
+    dist = torch.cat([torch.zeros(n_rays, 1, device=dev), dist], 1).contiguous()
+    num = torch.full((n_rays,), S, dtype=torch.int32, device=dev)
     cum = torch.cumsum(num, 0).to(torch.int32)
     bounds = torch.stack([cum - num, cum], -1).contiguous()
     dirs = d.expand(-1, S, -1).reshape(n_all, 3).contiguous()
-    return sampled_pts.view(n_all, 3), dirs, dist.view(n_all), sampled_t, bounds
+    out = (sampled_pts.view(n_all, 3), dirs, dist.view(n_all), sampled_t, bounds)
+    return tuple(x.to(out_dev) for x in out)
 
 
 class RenderResult:
@@ -256,7 +260,7 @@ class Renderer(torch.nn.Module):
         self.scene_field = Hash3DAnchored(L, F, log2_T, level_stride, gen, feat_init)
         self.shader = SHShader()
         self.app_emb = torch.nn.Parameter(torch.randn(n_images, 16, generator=gen) * 0.1)
-        self.cumsum_device = None  # see get_samples
+        self.sampler_device = None  # see get_samples
 
     @staticmethod
     def density_act(x):
@@ -265,7 +269,7 @@ class Renderer(torch.nn.Module):
     def render(self, rays_o, rays_d, emb_idx, mode, noise=None, bg_color=None):
         n_rays = rays_o.shape[0]
         pts, dirs, dt, t, bounds = get_samples(
-            rays_o, rays_d, noise if mode == TRAIN else None, self.S, self.step, self.cumsum_device)
+            rays_o, rays_d, noise if mode == TRAIN else None, self.S, self.step, self.sampler_device)
         if bg_color is None:
             bg_color = torch.full((n_rays, 3), 0.5)  # VALIDATE, renderer.cpp:44
         # ---- first pass: early stop (renderer.cpp:58-90)

@@ -52,14 +52,15 @@ def _close(a, b, rtol, atol_frac=1e-5):
 
 
 def _close_samples(a, b):
-    """Per-sample weights of two parties whose sample POSITIONS differ.  The reference forms t by a
-    device cumsum of 1024 f32 steps (a parallel scan; the oracle and the HIP sampler add
-    sequentially), so positions differ by a few 1e-6 (bounded where this is used) and a
-    random-valued table turns that into ~1e-3 relative differences of individual densities, a few
-    times that in the tail.  That this one op is the cause is shown in the dense leg below: with the
-    oracle's cumsum run where the reference runs it, per-sample weights agree to 1e-4.  Integrated
-    quantities (colours, depths, loss) are held to 1e-4 either way; individual weights at differing
-    positions to 1e-4 in the median and 2e-3 in relative L2."""
+    """Per-sample weights of two parties whose sample POSITIONS differ.  The reference forms d^ and t
+    with linalg_norm and a cumsum of 1024 f32 steps on its device (a parallel scan; the oracle runs
+    the same ops on the CPU, the HIP sampler adds along a wave), so positions differ by a few
+    1e-7..1e-6 (bounded where this is used), and because dt is the norm of the DIFFERENCE of
+    neighbouring positions (quirk Q7) its rounding is re-drawn at the 1e-4..1e-3 level -- more in the
+    tail of a ray.  That the sampler's op placement is the whole cause is shown in the test below:
+    with the oracle's sampler ops run where the reference runs them, per-sample weights agree to
+    1e-4.  Integrated quantities (colours, depths, loss) are held to 1e-4 either way; individual
+    weights at differing positions to 1e-4 in the median and 2e-3 in relative L2."""
     rel = (a - b).abs() / b.abs().clamp_min(1e-12)
     assert float(rel.median()) < 1e-4, float(rel.median())
     assert float((a - b).norm() / b.norm()) < 2e-3
@@ -121,12 +122,13 @@ def test_reference_renderer_train_matches_oracle_and_this_renderer(host, dev, tm
     _close(ref["colors"], res.colors.detach(), 1e-4)
     _close(ref["depths"], res.depths.detach(), 1e-4)
     _close_samples(ref["weights"], res.weights.detach())
-    # ... and with IDENTICAL positions: the oracle's t formed by the same device cumsum the reference
-    # calls (src/points_sampler.cpp:38) -- per-sample weights at the north star's 1e-4
-    oracle.cumsum_device = dev
+    # ... and with IDENTICAL positions: the oracle's sampler ops (src/points_sampler.cpp:24-48:
+    # linalg_norm, cumsum, diff / norm) run on the device the reference runs them on, everything
+    # downstream still on the CPU -- per-sample weights at the north star's 1e-4
+    oracle.sampler_device = dev
     with torch.no_grad():
         res_same = oracle.render(o, d, emb, R.TRAIN, noise.cpu(), bg.cpu())
-    oracle.cumsum_device = None
+    oracle.sampler_device = None
     assert torch.equal(ref["idx_start_end"], res_same.idx_start_end)
     _close(ref["weights"], res_same.weights, 1e-4)
     _close(ref["colors"], res_same.colors, 1e-4)
