@@ -51,6 +51,8 @@ constexpr int kCombineRepeats = 448;       // ... or lanes (of the 768 that have
 constexpr int kSplitBlock = 512;       // pass B: four workgroups per CU (it is latency-bound)
 constexpr int kSplitQueueWords = 9216;   // 36 KiB: four workgroups per CU
 constexpr int kSplitRegions = 2;       // regions a wave of pass B ingests per round
+constexpr int kSplitSpill = 128;       // pass B: records past a full sub-slice queue wait here (exactly
+                                       // summed like the rest) instead of becoming float atomics
 constexpr int kMaxBuckets = 64;
 constexpr int kMaxLog2Sub = 6;
 
@@ -708,6 +710,12 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
   constexpr int kWaves = kSplitBlock / 64;
   __shared__ __attribute__((aligned(16))) uint32_t queue[kSplitQueueWords];
   __shared__ uint32_t qcount[64], cursor[64];
+  // records that found their sub-slice queue full: {sub << 16 | row in slice, values}; they are
+  // appended to their runs one by one after the queues (a slice that carries a few times the mean
+  // load -- coarse levels, where a slice owns a dozen distinct rows -- overflows its queue by a
+  // handful of records per round)
+  __shared__ uint32_t spill[kSplitSpill * KW];
+  __shared__ uint32_t spill_count;
   const int bucket = blockIdx.x, l = blockIdx.y, part = blockIdx.z;
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
@@ -726,6 +734,7 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
     qcount[threadIdx.x] = 0u;
     cursor[threadIdx.x] = 0u;
   }
+  if (threadIdx.x == 0) spill_count = 0u;
   __syncthreads();
 
   for (int64_t t0 = t_begin; t0 < t_end; t0 += (int64_t)kWaves * kSplitRegions) {
@@ -754,9 +763,16 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
           if (slot < (uint32_t)Q) {
             store_record<F>(queue + (size_t)sub * Q * KW, Q, slot, local, v[u]);
           } else {
-            apply_record_atomic<F>(gbase, row0 + r[u], v[u], a.inv_scale);
-            if (a.stats) atomicAdd(a.stats + 4 * l + 3, 1u);
-            if (a.overflow) atomicAdd(a.overflow, 1ull);
+            const uint32_t sp = atomicAdd(&spill_count, 1u);
+            if (sp < (uint32_t)kSplitSpill) {
+              spill[sp * KW] = (sub << 16) | local;
+#pragma unroll
+              for (int j = 0; j < VW; j++) spill[sp * KW + 1 + j] = v[u][j];
+            } else {
+              apply_record_atomic<F>(gbase, row0 + r[u], v[u], a.inv_scale);
+              if (a.stats) atomicAdd(a.stats + 4 * l + 3, 1u);
+              if (a.overflow) atomicAdd(a.overflow, 1ull);
+            }
           }
         }
       }
@@ -784,6 +800,30 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
       }
     }
     __syncthreads();
+    const uint32_t n_spill = min(spill_count, (uint32_t)kSplitSpill);  // (block-uniform)
+    if (n_spill) {
+      for (uint32_t i = threadIdx.x; i < n_spill; i += kSplitBlock) {
+        const uint32_t head = spill[i * KW], sub = head >> 16, local = head & 0xffffu;
+        uint32_t vv[VW];
+#pragma unroll
+        for (int j = 0; j < VW; j++) vv[j] = spill[i * KW + 1 + j];
+        const int slice = (bucket << a.log2_sub) + (int)sub;
+        const uint32_t pos = atomicAdd(&cursor[sub], 1u);
+        if (slice < a.n_slices && pos < (uint32_t)a.cap2) {
+          uint32_t * run = a.b_records + (((size_t)l * a.n_slices + slice) * a.n_parts + part) * (size_t)a.cap2 * KW;
+          store_record<F>(run, a.cap2, pos, local, vv);
+        } else {
+          apply_record_atomic<F>(gbase, row0 + sub * kRows + local, vv, a.inv_scale);
+          if (a.stats) atomicAdd(a.stats + 4 * l + 2, 1u);
+          if (a.overflow) atomicAdd(a.overflow, 1ull);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) spill_count = 0u;
+      // cursors that ran past the run's capacity through the adds above
+      if (threadIdx.x < 64) cursor[threadIdx.x] = min(cursor[threadIdx.x], (uint32_t)a.cap2);
+      __syncthreads();
+    }
   }
   if ((int)threadIdx.x < n_sub) {
     const int slice = (bucket << a.log2_sub) + threadIdx.x;

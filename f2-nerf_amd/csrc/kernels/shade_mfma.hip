@@ -21,7 +21,14 @@
 //     registers are written with ds_write_b32 (lanes of a quarter = consecutive samples) and read back
 //     as float4 = four consecutive k-steps (k-step t of quarter q = sample 16(t/4) + 4q + t%4).
 //
-// Per 64-sample stride: 560 MFMAs (18 K cycles/SIMD), ~170 KB of LDS traffic.  Accumulators of all
+// The 3-wide output layer is NOT on the matrix cores: as a 16-row MFMA operand 13 of its 16 rows are
+// padding (round 2: 23-29 % of all issued products).  Each lane holds 16 hidden neurons of 4 samples
+// in the Q-layout, so o[c][s] = sum_j w2[c][j] relu(pre[j][s]) is 48 vector FMAs per 16-neuron tile
+// into per-quarter partial sums, and ONE product per (c, sample tile) with an all-ones A operand adds
+// the four quarters (the MFMA's k axis) and hands the sum to every lane: 12 products instead of 64.
+// Its two backward products (d w2, and d_hid = w2^T d_o) are vector FMAs on the same registers.
+//
+// Per 64-sample stride: 428 MFMAs + ~580 vector FMAs, ~130 KB of LDS traffic.  Accumulators of all
 // parameter gradients stay in registers across the strides of a (persistent) wave; one atomic flush
 // per wave at the end.
 #include "shade_mfma.hiph"
@@ -54,12 +61,11 @@ struct MShape
   // weight operand slots (64 floats each, one per lane)
   static constexpr int oWA1 = 0;               // [t]        w_h[m][q*kS1 + t]
   static constexpr int oWA2 = oWA1 + kS1;      // [M*8 + t]  w1[16M+m][kappa2(t, q)]
-  static constexpr int oWA3 = oWA2 + 32;       // [M*4 + r]  w2[m/4][16M+4q+r] on rows m = 0, 4, 8
-  static constexpr int oWA4 = oWA3 + 16;       // [M]        w2[q][16M+m]            (q < 3)
-  static constexpr int oWA5 = oWA4 + 4;        // [M*4 + r]  w1[16M+4q+r][m]
+  static constexpr int oWA5 = oWA2 + 32;       // [M*4 + r]  w1[16M+4q+r][m]
   static constexpr int oWA6 = oWA5 + 16;       // [M'*4 + r] w_h[4q+r][16M'+m]
   static constexpr int kSlots = oWA6 + kM6 * 4;
-  static constexpr int oBh = kSlots * 64;      // b_h[16]
+  static constexpr int oW2Q = kSlots * 64;     // [M][q][c] float4 over r: w2[c][16M+4q+r] (vector output layer)
+  static constexpr int oBh = oW2Q + 4 * 4 * 3 * 4;  // b_h[16]
   static constexpr int oB1 = oBh + 16;         // b1[64]
   static constexpr int oB2 = oB1 + 64;         // b2[3], 0
   static constexpr int kWFloats = oB2 + 4;
@@ -70,8 +76,9 @@ struct MShape
   static constexpr int oXS = 0;                // [32][kP]  X
   static constexpr int oES = oXS + 32 * kP;    // [C][kP]   enc
   static constexpr int oPS = oES + kM6 * 16 * kP;  // [16][kP]  one M-tile of relu(pre) / d_hid, then d_h
-  static constexpr int oDS = oPS + 16 * kP;    // [4][kP]   d_o rows 0..2, row 3 = 0
-  static constexpr int kWaveFloats = oDS + 4 * kP;
+  static constexpr int oDS = oPS + 16 * kP;    // [4][kP]   d_o rows 0..2
+  static constexpr int kAccs = 89 + 4 * kM6;   // accumulator registers a wave hands to wave 0 at the end
+  static constexpr int kWaveFloats = (oDS + 4 * kP > kAccs * 64) ? oDS + 4 * kP : kAccs * 64;
   // One wave per SIMD.  The live state of a stride (64 pre-activations, 65 accumulators, operands in
   // flight) does not fit the 256 registers a wave gets at two per SIMD: hipcc then parks the
   // accumulators in scratch and every reload drains vmcnt (2.0-2.6 ms per 8.4 M samples); with 512
@@ -82,8 +89,10 @@ struct MShape
   static_assert(kLdsFloats * 4 <= 160 * 1024, "LDS budget");
 };
 
-// No instruction crosses a phase boundary: 5 % faster than letting the scheduler mix phases
-// (F2N_SHADE_VARIANT=1 lifts the fences, for measurements)
+// V & 1: the scheduler may mix the phases of a stride (the default since the output layer moved to
+// the vector pipe: 1.47 vs 1.54 ms per 8.4 M samples -- its vector phases then fill the gaps of the
+// matrix phases around them; with every phase on the matrix cores, round 2, the fenced form was 5 %
+// faster).  F2N_OPT_SHADE_VARIANT = 1 puts the fences back, for measurements.
 template <int V>
 __device__ __forceinline__ void phase_fence_v()
 {
@@ -172,16 +181,10 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
     if (slot < S::oWA2) {
       const int t = slot - S::oWA1;
       v = p_w_h[m * C + q * kS1 + t];
-    } else if (slot < S::oWA3) {
+    } else if (slot < S::oWA5) {
       const int M = (slot - S::oWA2) >> 3, t = (slot - S::oWA2) & 7;
       const int k = (t < 4) ? 4 * q + t : 16 + 4 * q + (t - 4);
       v = p_w1[(16 * M + m) * kIn2 + k];
-    } else if (slot < S::oWA4) {
-      const int M = (slot - S::oWA3) >> 2, r = (slot - S::oWA3) & 3;
-      v = ((m & 3) == 0 && m < 12) ? p_w2[(m >> 2) * kHid + 16 * M + 4 * q + r] : 0.f;
-    } else if (slot < S::oWA5) {
-      const int M = slot - S::oWA4;
-      v = (q < 3) ? p_w2[q * kHid + 16 * M + m] : 0.f;
     } else if (slot < S::oWA6) {
       const int M = (slot - S::oWA5) >> 2, r = (slot - S::oWA5) & 3;
       v = p_w1[(16 * M + 4 * q + r) * kIn2 + m];
@@ -190,6 +193,10 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
       v = (16 * M + m < C) ? p_w_h[(4 * q + r) * C + 16 * M + m] : 0.f;
     }
     lds_w[i] = v;
+  }
+  if (threadIdx.x < 192) {  // output-layer weights of the vector path: [M][q][c][r] = w2[c][16M+4q+r]
+    const int i = threadIdx.x, r = i & 3, c = (i >> 2) % 3, Mq = i / 12;
+    lds_w[S::oW2Q + i] = p_w2[c * kHid + 16 * (Mq >> 2) + 4 * (Mq & 3) + r];
   }
   if (threadIdx.x < 16) lds_w[S::oBh + threadIdx.x] = p_b_h[threadIdx.x];
   if (threadIdx.x < 64) lds_w[S::oB1 + threadIdx.x] = p_b1[threadIdx.x];
@@ -203,7 +210,6 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
   float * ES = tile + S::oES;
   float * PS = tile + S::oPS;
   float * DS = tile + S::oDS;
-  DS[3 * kP + lane] = 0.f;  // the zero row read by lanes m >= 3 in the d w2 product
   if constexpr (C % 16 != 0) {  // enc rows beyond C (read as zeros by the d w_h product)
     for (int r = C; r < kM6 * 16; r++) ES[r * kP + lane] = 0.f;
   }
@@ -212,13 +218,19 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
   const float * wop = lds_w + lane;  // slot s of this lane: wop[s * 64]
   // With 512 registers the weight operands stay in registers for the whole kernel (C <= 32: 84 of
   // them); read just in time from LDS they cost a full LDS latency every eight products.
+  // (the head and hidden layers' operands, slots below oWA5; the data-gradient operands of the last
+  // two phases are read when needed: the vector phases of the output layer need their registers)
   constexpr bool kWReg = C <= 32;
-  float wreg[kWReg ? S::kSlots : 1];
+  constexpr int kRegLo = S::oWA2, kRegHi = S::oWA5;  // the hidden layer's 32 slots
+  float wreg[kWReg ? kRegHi - kRegLo : 1];
   if constexpr (kWReg) {
 #pragma unroll
-    for (int i = 0; i < S::kSlots; i++) wreg[i] = wop[i * 64];
+    for (int i = kRegLo; i < kRegHi; i++) wreg[i - kRegLo] = wop[i * 64];
   }
-  auto W = [&](int slot) { return kWReg ? wreg[kWReg ? slot : 0] : wop[slot * 64]; };
+  auto W = [&](int slot) {
+    const bool in_reg = kWReg && slot >= kRegLo && slot < kRegHi;
+    return in_reg ? wreg[in_reg ? slot - kRegLo : 0] : wop[slot * 64];
+  };
   // byte offsets of this quarter's first enc / d_enc row (quarter q owns channels q*kS1.., rows 4q..)
   using Off = typename RowOffset<WIDE>::type;
   const Off cE = (Off)((int64_t)(q * kS1) * n * 4), cD = (Off)((int64_t)(4 * q) * n * 4);
@@ -227,7 +239,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
   // per-lane accumulators that live across all strides of this wave
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 acc_w1[4][2];   // d w1[16M+4q+r][16N+m]
-  f32x4 acc_w2[4];      // d w2[4q+r][16M+m], rows 0..2 are real
+  f32x4 acc_w2[3][4];   // d w2[c][16M+4q+r], partial over this lane's samples (vector FMAs)
   f32x4 acc_wh[kM6];    // d w_h[4q+r][16N+m]
   float acc_b1[4];      // d b1[16M+m], partial over this quarter's k-steps (S-layout reads)
   f32x4 acc_bh = zero4; // d b_h[4q+r]
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
 #pragma unroll
   for (int M = 0; M < 4; M++) {
     acc_w1[M][0] = acc_w1[M][1] = zero4;
-    acc_w2[M] = zero4;
+    acc_w2[0][M] = acc_w2[1][M] = acc_w2[2][M] = zero4;
     acc_b1[M] = 0.f;
   }
 #pragma unroll
@@ -364,86 +376,86 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
       }
     }
 
-    // ---- the next stride's inputs (their registers are free since the head layer / the SH block)
-    load_inputs(st + wave_count, eB, img, dir);
-    issue_fence();
-
     phase_fence_v<V>();
-    // ---- output layer on rows 0, 4, 8: o[c = q][s] in register 0, then d_o
+    // ---- output layer on the vector pipe: per-quarter partial sums over this lane's 16 hidden
+    // neurons (pre becomes relu(pre): its sign is all the ReLU's backward needs), the four quarters
+    // summed by one all-ones product per (c, sample tile); then d_o for c = q
     float d_o[4];
     {
-      float g_rgb[4];  // d_rgb[s][c = q]: in flight during the 64 products below
+      float g_rgb[4];  // d_rgb[s][c = q]: in flight during the sums below
 #pragma unroll
       for (int T = 0; T < 4; T++) g_rgb[T] = ld_row(d_rgb, 3 * offS[T] + ((q < 3) ? 4 * q : 8));
       issue_fence();
-      f32x4 o[4];
+      float po[3][4];
 #pragma unroll
-      for (int T = 0; T < 4; T++) {
-        o[T] = zero4;
-        o[T][0] = lds_w[S::oB2 + q];
+      for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int T = 0; T < 4; T++) po[c][T] = 0.f;
+#pragma unroll
+      for (int M = 0; M < 4; M++) {
+        f32x4 wq[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+          wq[c] = *reinterpret_cast<const f32x4 *>(lds_w + S::oW2Q + ((M * 4 + q) * 3 + c) * 4);
+#pragma unroll
+        for (int T = 0; T < 4; T++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float p = relu(pre[M][T][r]);
+            pre[M][T][r] = p;
+#pragma unroll
+            for (int c = 0; c < 3; c++) po[c][T] = __builtin_fmaf(wq[c][r], p, po[c][T]);
+          }
       }
-#pragma unroll
-      for (int M = 0; M < 4; M++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float a = W(S::oWA3 + M * 4 + r);
-#pragma unroll
-          for (int T = 0; T < 4; T++) o[T] = mfma16(a, relu(pre[M][T][r]), o[T]);
-        }
+      const float b2q = lds_w[S::oB2 + q];
 #pragma unroll
       for (int T = 0; T < 4; T++) {
-        const float sg = 1.f / (1.f + expf(-o[T][0]));
+        const float s0 = mfma16(1.f, po[0][T], zero4)[0];
+        const float s1 = mfma16(1.f, po[1][T], zero4)[0];
+        const float s2 = mfma16(1.f, po[2][T], zero4)[0];
+        const float o = ((q == 0) ? s0 : (q == 1) ? s1 : s2) + b2q;
+        const float sg = 1.f / (1.f + expf(-o));
         const float g = (vT[T] && q < 3) ? g_rgb[T] : 0.f;
         d_o[T] = g * (1.f + 2.f * kEps) * sg * (1.f - sg);
         acc_b2 += d_o[T];
         if (q < 3) DS[q * kP + 16 * T + m] = d_o[T];
       }
     }
+    wave_lds_sync();
 
     phase_fence_v<V>();
-    // ---- d w2[c][j] += sum_s d_o[c][s] relu(pre)[j][s], one 16-neuron tile at a time.  The LDS
-    // executes one wave's operations in order, so tile M+1 is written right behind the reads of
-    // tile M (no wait) and its latency hides behind tile M's products.
+    // ---- d w2[c][j] += sum_s d_o[c][s] relu(pre)[j][s] and d_hid[j][s] = [pre > 0] sum_c w2[c][j]
+    // d_o[c][s], both on the registers that hold relu(pre): d_o of all three colours comes back from
+    // the LDS tile (lane (q, m) computed colour q only); d_hid replaces pre
     {
-      const int arow = (m < 3) ? m : 3;
-      auto put = [&](int M) {
+      float doc[3][4];
 #pragma unroll
-        for (int T = 0; T < 4; T++)
+      for (int c = 0; c < 3; c++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) PS[(4 * q + r) * kP + 16 * T + m] = relu(pre[M][T][r]);
-      };
-      put(0);
-      wave_lds_sync();
+        for (int T = 0; T < 4; T++) doc[c][T] = DS[c * kP + 16 * T + m];
 #pragma unroll
       for (int M = 0; M < 4; M++) {
-        f32x4 a4[4], b4[4];
+        f32x4 wq[3];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          a4[u] = *reinterpret_cast<const f32x4 *>(DS + arow * kP + 16 * u + 4 * q);
-          b4[u] = *reinterpret_cast<const f32x4 *>(PS + m * kP + 16 * u + 4 * q);
+        for (int c = 0; c < 3; c++)
+          wq[c] = *reinterpret_cast<const f32x4 *>(lds_w + S::oW2Q + ((M * 4 + q) * 3 + c) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            float t = doc[c][0] * pre[M][0][r];
+#pragma unroll
+            for (int T = 1; T < 4; T++) t = __builtin_fmaf(doc[c][T], pre[M][T][r], t);
+            acc_w2[c][M][r] += t;
+          }
+#pragma unroll
+          for (int T = 0; T < 4; T++) {
+            float dh = wq[0][r] * doc[0][T];
+            dh = __builtin_fmaf(wq[1][r], doc[1][T], dh);
+            dh = __builtin_fmaf(wq[2][r], doc[2][T], dh);
+            pre[M][T][r] = (pre[M][T][r] > 0.f) ? dh : 0.f;
+          }
         }
-        wave_lds_sync();
-        if (M < 3) {
-          put(M + 1);
-          wave_lds_sync();
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-          for (int k = 0; k < 4; k++) acc_w2[M] = mfma16(a4[u][k], b4[u][k], acc_w2[M]);
-      }
-    }
-
-    phase_fence_v<V>();
-    // ---- back through the output layer and the ReLU: d_hid replaces pre
-#pragma unroll
-    for (int M = 0; M < 4; M++) {
-      const float a = W(S::oWA4 + M);
-#pragma unroll
-      for (int T = 0; T < 4; T++) {
-        const f32x4 dh = mfma16(a, d_o[T], zero4);
-#pragma unroll
-        for (int r = 0; r < 4; r++) pre[M][T][r] = (pre[M][T][r] > 0.f) ? dh[r] : 0.f;
       }
     }
 
@@ -484,6 +496,12 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
         }
       }
     }
+
+    // ---- the next stride's inputs (their registers are free since the head layer / the SH block;
+    // issued behind the vector phases and the d w1 product, which leave no registers for them: the
+    // 128 products of the last three phases, ~4 K cycles, cover the latency)
+    load_inputs(st + wave_count, eB, img, dir);
+    issue_fence();
 
     phase_fence_v<V>();
     // ---- d_X rows 0..15 = w1[:, 0:16]^T . d_hid   (the SH inputs carry no gradient)
@@ -590,7 +608,9 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
 #pragma unroll
           for (int r = 0; r < 4; r++) acc_w1[M][N][r] = fn(acc_w1[M][N][r], i++);
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc_w2[M][r] = fn(acc_w2[M][r], i++);
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc_w2[c][M][r] = fn(acc_w2[c][M][r], i++);
         acc_b1[M] = fn(acc_b1[M], i++);
       }
 #pragma unroll
@@ -601,7 +621,7 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
       for (int r = 0; r < 4; r++) acc_bh[r] = fn(acc_bh[r], i++);
       acc_b2 = fn(acc_b2, i++);
     };
-    static_assert((57 + 4 * kM6) * 64 <= S::kWaveFloats, "the accumulators fit a wave's tile region");
+    static_assert(S::kAccs * 64 <= S::kWaveFloats, "the accumulators fit a wave's tile region");
     wave_lds_sync();
     if (wave != 0) each_acc([&](float v, int i) { tile[i * 64 + lane] = v; return v; });
     __syncthreads();
@@ -619,10 +639,13 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 4; r++)
         atomicAdd(g_w1 + (16 * M + 4 * q + r) * kIn2 + 16 * N + m, acc_w1[M][N][r]);
-    if (q == 0) {
 #pragma unroll
-      for (int r = 0; r < 3; r++) atomicAdd(g_w2 + r * kHid + 16 * M + m, acc_w2[M][r]);
-    }
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float t = quarter_sum(acc_w2[c][M][r]);  // over the quarter's 16 sample columns
+        if (m == 0) atomicAdd(g_w2 + c * kHid + 16 * M + 4 * q + r, t);
+      }
     {
       float t = acc_b1[M];  // lane (q, m): neuron 16M+m, this quarter's samples
       t += __shfl_xor(t, 16);
@@ -649,10 +672,13 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
 
 // ---- forward on the matrix cores ------------------------------------------------------------------
 // The forward third of the kernel above (head, hidden and output layer in the Q-layout, no lane
-// movement), two waves per SIMD: no accumulators live across strides, so 256 registers suffice and
-// the second wave hides the first one's loads.  LDS: the three forward weight operands (56 slots at
+// movement), three waves per SIMD: no accumulators live across strides and the other waves hide one
+// wave's loads.  The output layer STAYS on the matrix cores here (rows 0, 4, 8 of a 16-row operand):
+// the vector form the backward uses was measured and lost, 0.64 ms (0.62 at two waves per SIMD)
+// against 0.55 per 8.4 M samples -- 52 products fewer but 200 vector instructions more and, at 168
+// registers, spills; this kernel waits on latencies, not on the matrix pipe.  LDS: the three forward weight operands (56 slots at
 // C = 32) + a 16-row tile per wave that moves SH16(dir) from lane = sample into the Q-layout.
-template <int C>
+template <int C, int W = 12>
 struct FShape
 {
   static_assert(C % 8 == 0 && C <= 64, "MFMA path: C must be 8, 16, 32 or 64");
@@ -661,12 +687,12 @@ struct FShape
   static constexpr int oBh = kSlots * 64, oB1 = oBh + 16, oB2 = oB1 + 64, kWFloats = oB2 + 4;
   static constexpr int kP = 68;             // [16][kP] SH tile per wave (b32 accesses only)
   static constexpr int kWaveFloats = 16 * kP;
-  static constexpr int kWaves = 12;  // three per SIMD: the kernel needs 136 registers
+  static constexpr int kWaves = W;   // 12 = three per SIMD (the kernel needs 136 registers), 8 = two
   static constexpr int kLdsFloats = kWFloats + kWaves * kWaveFloats;
 };
 
-template <int C, bool WIDE>
-__global__ __launch_bounds__(FShape<C>::kWaves * 64) void shade_fwd_mfma_kernel(
+template <int C, bool WIDE, int W>
+__global__ __launch_bounds__(W * 64) void shade_fwd_mfma_kernel(
   const float * __restrict__ enc, const float * __restrict__ dirs,
   const int32_t * __restrict__ sample_img, const float * __restrict__ p_w_h,
   const float * __restrict__ p_b_h, const float * __restrict__ p_w1,
@@ -674,7 +700,7 @@ __global__ __launch_bounds__(FShape<C>::kWaves * 64) void shade_fwd_mfma_kernel(
   const float * __restrict__ p_b2, const float * __restrict__ p_emb, float * __restrict__ logit,
   float * __restrict__ rgb, float * __restrict__ pre_out, int64_t n)
 {
-  using S = FShape<C>;
+  using S = FShape<C, W>;
   constexpr int kS1 = S::kS1, kP = S::kP;
   __shared__ __attribute__((aligned(16))) float lds_all[S::kLdsFloats];
   float * lds_w = lds_all;
@@ -861,10 +887,10 @@ int launch_shade_bwd_mfma(
       g_b1, g_w2, g_b2, g_app_emb, n);                                                               \
   }
 #define F2N_LAUNCH_MFMA(CC)                                \
-  if (wide) F2N_LAUNCH_MFMA_V(CC, 0, true)                 \
+  if (wide) F2N_LAUNCH_MFMA_V(CC, 1, true)                 \
   else switch (variant) {                                  \
-      case 1: F2N_LAUNCH_MFMA_V(CC, 1, false) break;       \
-      default: F2N_LAUNCH_MFMA_V(CC, 0, false) break;      \
+      case 1: F2N_LAUNCH_MFMA_V(CC, 0, false) break;       \
+      default: F2N_LAUNCH_MFMA_V(CC, 1, false) break;      \
     }
   switch (C) {
     case 8: F2N_LAUNCH_MFMA(8) break;
@@ -888,16 +914,19 @@ int launch_shade_fwd_mfma(
   if (app_emb && (reinterpret_cast<uintptr_t>(app_emb) & 15u)) return F2N_E_INVALID_ARG;
   if (n >= ((int64_t)1 << 28)) return F2N_E_UNSUPPORTED;  // 32-bit per-sample offsets
   const bool wide = (int64_t)(pre_cm ? 64 : C) * n >= ((int64_t)1 << 30);  // row offsets beyond 32 bits
-#define F2N_LAUNCH_FWD_W(CC, WW)                                                                   \
+  const bool two_per_simd = f2n_get_option(F2N_OPT_SHADE_VARIANT) == 2;
+#define F2N_LAUNCH_FWD_W(CC, WW, KW)                                                               \
   {                                                                                                \
-    constexpr int kW = FShape<CC>::kWaves;                                                         \
+    constexpr int kW = KW;                                                                         \
     const unsigned grid = (unsigned)std::min<int64_t>(256, (n_strides + kW - 1) / kW);             \
     hipLaunchKernelGGL(                                                                            \
-      (shade_fwd_mfma_kernel<CC, WW>), dim3(grid), dim3(kW * 64), 0, stream, enc_cm, dirs,         \
+      (shade_fwd_mfma_kernel<CC, WW, KW>), dim3(grid), dim3(kW * 64), 0, stream, enc_cm, dirs,     \
       sample_img, w_h, b_h, w1, b1, w2, b2, app_emb, logit, rgb, pre_cm, n);                       \
   }
-#define F2N_LAUNCH_FWD(CC) \
-  if (wide) F2N_LAUNCH_FWD_W(CC, true) else F2N_LAUNCH_FWD_W(CC, false)
+#define F2N_LAUNCH_FWD(CC)                                                   \
+  if (wide) F2N_LAUNCH_FWD_W(CC, true, 12)                                   \
+  else if (two_per_simd) F2N_LAUNCH_FWD_W(CC, false, 8)                      \
+  else F2N_LAUNCH_FWD_W(CC, false, 12)
   switch (C) {
     case 8: F2N_LAUNCH_FWD(8) break;
     case 16: F2N_LAUNCH_FWD(16) break;

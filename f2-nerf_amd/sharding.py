@@ -28,16 +28,19 @@ def view_for(step, rank, world, n_images):
     return (step * world + rank) % n_images
 
 
-def reduce_error_stats(sq_err_sum, n_values, dist=None, group=None):
-    """all-reduce(SUM) of [sum sq err, n] -> (global sum, global n) as a float64 tensor [2]."""
+def reduce_error_stats(sq_err_sum, n_values, dist=None, group=None, async_op=False):
+    """all-reduce(SUM) of [sum sq err, n] -> (global sum, global n) as a float64 tensor [2].
+    async_op: return (tensor, work) without making the caller's stream wait for the collective; the
+    tensor holds the global sums once work.wait() has returned (work is None without a group)."""
     dev = sq_err_sum.device if torch.is_tensor(sq_err_sum) else "cpu"
     stat = torch.stack([torch.as_tensor(sq_err_sum, dtype=torch.float64, device=dev).reshape(()),
                         torch.tensor(float(n_values), dtype=torch.float64, device=dev)])
     # (also with a single rank: a one-rank group still runs the backend's collective, which is how
     # bench.py --gpus 1 exercises RCCL on a one-GPU box)
+    work = None
     if dist is not None and dist.is_initialized():
-        dist.all_reduce(stat, group=group)
-    return stat
+        work = dist.all_reduce(stat, group=group, async_op=async_op)
+    return (stat, work) if async_op else stat
 
 
 def psnr_from_stats(stat):

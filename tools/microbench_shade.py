@@ -30,6 +30,9 @@ def t(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 pre = torch.empty(64, n, device=dev)
 print("fwd matrix-core (default) %.3f ms" % t(lambda: capi.call("shade_fwd", enc, C, dirs, img, *P, emb, logit, rgb, None, n)))
+capi.set_option("SHADE_VARIANT", 2)
+print("fwd matrix-core, 2 waves/SIMD %.3f ms" % t(lambda: capi.call("shade_fwd", enc, C, dirs, img, *P, emb, logit, rgb, None, n)))
+capi.set_option("SHADE_VARIANT", 0)
 capi.set_option("SHADE_FWD", 1)
 print("fwd vector                %.3f ms" % t(lambda: capi.call("shade_fwd", enc, C, dirs, img, *P, emb, logit, rgb, None, n)))
 capi.set_option("SHADE_FWD", 0)
