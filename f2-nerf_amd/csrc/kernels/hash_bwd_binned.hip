@@ -23,8 +23,15 @@
 //                    then add the slice into the table gradient with contiguous float atomics (the
 //                    reference's level windows overlap, quirk Q2, so it must be an add).
 //
-// Capacities never affect results: a record that finds its queue or region full is applied directly
-// with global float atomics (order-dependent in the last bit, like the reference's own atomics).
+// Capacities never affect results.  Two-level tables: a record that finds its queue, region or run
+// full goes to the ARENA of its (level, bucket) -- an append buffer in the workspace that the reduce
+// pass of every slice of that bucket scans after its own runs -- and is summed exactly like the rest;
+// only a record that finds the arena full as well is applied directly with a global float atomic.
+// Single-level tables apply a record that finds its queue full directly (measured: routing those
+// through an arena costs 1 ms per 8.4 M dense samples whose coarse levels overflow by design, and up
+// to 3 ms on a camera's adjacent pixels; their float atomics spread over the table).  A direct add
+// is order-dependent in the last bit, like the reference's own atomics, and counted
+// (f2n_hash_bwd_set_overflow_counter).
 #include "hash_grid.hiph"
 
 #include <algorithm>
@@ -53,6 +60,7 @@ constexpr int kSplitQueueWords = 9216;   // 36 KiB: four workgroups per CU
 constexpr int kSplitRegions = 2;       // regions a wave of pass B ingests per round
 constexpr int kSplitSpill = 128;       // pass B: records past a full sub-slice queue wait here (exactly
                                        // summed like the rest) instead of becoming float atomics
+constexpr int kArenaRecords = 32768;   // overflow arena per (level, bucket): records, at most
 constexpr int kMaxBuckets = 64;
 constexpr int kMaxLog2Sub = 6;
 
@@ -121,6 +129,55 @@ __device__ __forceinline__ void apply_record_atomic(
     const float v = h2f((uint16_t)val_channel_bits<F>(val, k));
     if (v != 0.f) atomicAdd(gbase + (int64_t)row * F + k, v * inv_scale);
   }
+}
+
+// The overflow arena of one (level, bucket): records {sub-slice << 16 | row in slice, values}, array of
+// structures.  Space is reserved per WAVE and bucket (one global atomic for all lanes of a wave that
+// overflow into the same bucket: a tile whose samples pile onto one cell overflows thousands of
+// records into one bucket, and one returning atomic per record on one word serialises at ~90 per
+// microsecond), and an arena that is already full is not asked again.
+struct Arena
+{
+  uint32_t * counts;   // [L][n_buckets]
+  uint32_t * records;  // [L][n_buckets][cap][KW]
+  int n_buckets, cap;
+};
+
+// Called by any subset of a wave's lanes (divergent callers welcome); false = no room, the caller
+// applies the record directly.
+template <int F>
+__device__ __forceinline__ bool arena_push(
+  const Arena & ar, int l, uint32_t bucket, uint32_t sub, uint32_t local, const uint32_t * val)
+{
+  constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
+  if (!ar.counts) return false;
+  bool done = false, ok = false;
+  while (!done) {  // one turn per distinct bucket among the calling lanes
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bucket);
+    if (bucket == b0) {
+      const unsigned long long m = __ballot(true);  // the calling lanes with this bucket
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi(
+        (uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      const size_t slot = (size_t)l * ar.n_buckets + b0;
+      uint32_t base = (uint32_t)ar.cap;
+      if (rank == 0) {
+        // (an L2-coherent load: never larger than the true count, so a stale value only costs the add)
+        if (__hip_atomic_load(ar.counts + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)ar.cap)
+          base = atomicAdd(ar.counts + slot, (uint32_t)__popcll(m));
+      }
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);  // the first calling lane has rank 0
+      const uint32_t pos = base + rank;
+      if (pos < (uint32_t)ar.cap) {
+        uint32_t * rec = ar.records + (slot * (size_t)ar.cap + pos) * KW;
+        rec[0] = (sub << 16) | local;
+#pragma unroll
+        for (int j = 0; j < VW; j++) rec[1 + j] = val[j];
+        ok = true;
+      }
+      done = true;
+    }
+  }
+  return ok;
 }
 
 template <int F>
@@ -213,6 +270,7 @@ struct BinArgs
   int n_buckets, bshift, groups, qcap, qcap_comb, combine;
   uint32_t * stats;  // optional [L][4] u32 counters (tools/ab_hash_bwd.py), else NULL
   unsigned long long * overflow;  // optional: += records applied with float atomics, else NULL
+  Arena arena;
 };
 
 // SAT: sum the saturated cell (0,0,0) in LDS (tables that take the split pass); a template
@@ -226,6 +284,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
 {
   constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
   constexpr uint32_t kSlots = 4096 / F;  // combine table: slots (tags), F 64-bit sums each
+  constexpr uint32_t kSliceRows = kBinAcc / F;  // rows of one reduce-pass slice
   // channel-major with an odd pitch, for the same bank reason as SliceAcc (F >= 2: 4096 + F words)
   auto comb_index = [](uint32_t slot, int k) { return (uint32_t)k * (kSlots + (F > 1 ? 1u : 0u)) + slot; };
   __shared__ __attribute__((aligned(16))) uint32_t queue[kBinQueueWords];
@@ -377,7 +436,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       if (slot < (uint32_t)cap)
         // (bucket < 64, cap * KW <= 32768: a 24-bit multiply is full rate, v_mul_lo_u32 a quarter)
         store_record<F>(queue + __umul24(bucket, (uint32_t)(cap * KW)), cap, slot, r & bmask, val);
-      else {
+      else if (!arena_push<F>(a.arena, l, bucket, (r & bmask) / kSliceRows, (r & bmask) % kSliceRows, val)) {
         apply_record_atomic<F>(gbase, r, val, a.inv_scale);
         if (a.overflow) atomicAdd(a.overflow, 1ull);
       }
@@ -700,6 +759,7 @@ struct SplitArgs
   int n_buckets, bshift, log2_sub, qcap, n_slices, tiles_per_part, n_parts, cap2;
   uint32_t * stats;  // optional [L][4] counters: [3] += records that overflowed a queue or a run
   unsigned long long * overflow;  // optional: += records applied with float atomics, else NULL
+  Arena arena;
 };
 
 template <int F>
@@ -769,9 +829,11 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
 #pragma unroll
               for (int j = 0; j < VW; j++) spill[sp * KW + 1 + j] = v[u][j];
             } else {
-              apply_record_atomic<F>(gbase, row0 + r[u], v[u], a.inv_scale);
               if (a.stats) atomicAdd(a.stats + 4 * l + 3, 1u);
-              if (a.overflow) atomicAdd(a.overflow, 1ull);
+              if (!arena_push<F>(a.arena, l, (uint32_t)bucket, sub, local, v[u])) {
+                apply_record_atomic<F>(gbase, row0 + r[u], v[u], a.inv_scale);
+                if (a.overflow) atomicAdd(a.overflow, 1ull);
+              }
             }
           }
         }
@@ -789,9 +851,11 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
         for (uint32_t i = fit + lane; i < c; i += 64) {  // run full: apply directly
           uint32_t rr, vv[VW];
           load_record<F>(queue + (size_t)sub * Q * KW, Q, i, rr, vv);
-          apply_record_atomic<F>(gbase, row0 + (uint32_t)sub * kRows + rr, vv, a.inv_scale);
           if (a.stats) atomicAdd(a.stats + 4 * l + 2, 1u);
-          if (a.overflow) atomicAdd(a.overflow, 1ull);
+          if (!arena_push<F>(a.arena, l, (uint32_t)bucket, (uint32_t)sub, rr, vv)) {
+            apply_record_atomic<F>(gbase, row0 + (uint32_t)sub * kRows + rr, vv, a.inv_scale);
+            if (a.overflow) atomicAdd(a.overflow, 1ull);
+          }
         }
       }
       if (lane == 0) {
@@ -813,9 +877,11 @@ __global__ __launch_bounds__(kSplitBlock) void hash_bwd_split_kernel(const Split
           uint32_t * run = a.b_records + (((size_t)l * a.n_slices + slice) * a.n_parts + part) * (size_t)a.cap2 * KW;
           store_record<F>(run, a.cap2, pos, local, vv);
         } else {
-          apply_record_atomic<F>(gbase, row0 + sub * kRows + local, vv, a.inv_scale);
           if (a.stats) atomicAdd(a.stats + 4 * l + 2, 1u);
-          if (a.overflow) atomicAdd(a.overflow, 1ull);
+          if (!arena_push<F>(a.arena, l, (uint32_t)bucket, sub, local, vv)) {
+            apply_record_atomic<F>(gbase, row0 + sub * kRows + local, vv, a.inv_scale);
+            if (a.overflow) atomicAdd(a.overflow, 1ull);
+          }
         }
       }
       __syncthreads();
@@ -924,12 +990,32 @@ __device__ __forceinline__ void flush_slice(
   }
 }
 
+// the records of this slice in the overflow arena of its (level, bucket)
+template <int F>
+__device__ __forceinline__ void accumulate_arena(
+  SliceAcc & acc, const Arena & ar, int l, uint32_t bucket, uint32_t sub)
+{
+  constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
+  if (!ar.counts) return;
+  const size_t slot = (size_t)l * ar.n_buckets + bucket;
+  const uint32_t n = min(ar.counts[slot], (uint32_t)ar.cap);  // (block-uniform)
+  const uint32_t * recs = ar.records + slot * (size_t)ar.cap * KW;
+  for (uint32_t i = threadIdx.x; i < n; i += kBinBlock) {
+    const uint32_t head = recs[(size_t)i * KW];
+    if ((head >> 16) != sub) continue;
+    uint32_t vv[VW];
+#pragma unroll
+    for (int j = 0; j < VW; j++) vv[j] = recs[(size_t)i * KW + 1 + j];
+    accumulate_record<F>(acc, head & 0xffffu, vv);
+  }
+}
+
 // single-level: the regions pass A wrote for (level, slice = bucket), one per tile
 template <int F, bool DISJOINT>
 __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
   const uint32_t * __restrict__ ws_records, const uint32_t * __restrict__ ws_counts,
   float * __restrict__ table_grad, uint32_t T, int64_t level_stride, float inv_scale, int n_slices,
-  int qcap, int64_t n_tiles)
+  int qcap, int64_t n_tiles, const Arena arena)
 {
   constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
   constexpr uint32_t kRows = kBinAcc / F;
@@ -1013,6 +1099,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
         if (f0 + 64u * u + lane < total) accumulate_record<F>(acc, r[u], v[u]);
     }
   }
+  accumulate_arena<F>(acc, arena, l, (uint32_t)sidx, 0u);
   __syncthreads();
   flush_slice<F, DISJOINT>(acc, gbase_slice, row_lo, T, inv_scale);
 }
@@ -1022,7 +1109,7 @@ template <int F, bool DISJOINT>
 __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_runs_kernel(
   const uint32_t * __restrict__ b_records, const uint32_t * __restrict__ b_counts,
   float * __restrict__ table_grad, uint32_t T, int64_t level_stride, float inv_scale, int n_slices,
-  int n_parts, int cap2)
+  int n_parts, int cap2, int log2_sub, const Arena arena)
 {
   constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
   constexpr uint32_t kRows = kBinAcc / F;
@@ -1053,6 +1140,8 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_runs_kernel(
         if (i0 + 64 * u + lane < cnt) accumulate_record<F>(acc, r[u], v[u]);
     }
   }
+  accumulate_arena<F>(
+    acc, arena, l, (uint32_t)sidx >> log2_sub, (uint32_t)sidx & ((1u << log2_sub) - 1u));
   __syncthreads();
   flush_slice<F, DISJOINT>(acc, gbase_slice, row_lo, T, inv_scale);
 }
@@ -1067,6 +1156,8 @@ struct BinPlan
   // per-chunk layout (for chunk_tiles tiles)
   int tiles_per_part = 0, n_parts = 0, cap2 = 0;
   int64_t a_counts_bytes = 0, a_records_bytes = 0, b_counts_bytes = 0, b_records_bytes = 0;
+  int64_t arena_counts_bytes = 0, arena_bytes = 0;
+  int arena_cap = 0;
   int64_t bytes = 0;
 };
 
@@ -1102,7 +1193,15 @@ void layout_for(BinPlan & pl, int L, int F, int64_t tiles)
     pl.b_counts_bytes = align256((int64_t)L * pl.n_slices * pl.n_parts * 4);
     pl.b_records_bytes = align256((int64_t)L * pl.n_slices * pl.n_parts * pl.cap2 * kw * 4);
   }
-  pl.bytes = pl.a_counts_bytes + pl.a_records_bytes + pl.b_counts_bytes + pl.b_records_bytes;
+  // the arena (two-level tables only) grows with the batch: 64 records per tile round and
+  // (level, bucket), 1024 .. kArenaRecords -- a percent of the record regions
+  pl.arena_cap = pl.log2_sub > 0
+                   ? (int)std::min<int64_t>(kArenaRecords, std::max<int64_t>(1024, 64 * tiles_g))
+                   : 0;
+  pl.arena_counts_bytes = pl.arena_cap ? align256((int64_t)L * pl.n_buckets * 4) : 0;
+  pl.arena_bytes = align256((int64_t)L * pl.n_buckets * pl.arena_cap * kw * 4);
+  pl.bytes = pl.a_counts_bytes + pl.a_records_bytes + pl.b_counts_bytes + pl.b_records_bytes +
+             pl.arena_counts_bytes + pl.arena_bytes;
 }
 
 // Capacities of the binned backward for (n, L, F, T); !ok means "not applicable".  workspace_bytes
@@ -1232,6 +1331,19 @@ extern "C" int f2n_hash_bwd_binned(
     uint32_t * b_counts = reinterpret_cast<uint32_t *>(w + pl.a_counts_bytes + pl.a_records_bytes);
     uint32_t * b_records =
       reinterpret_cast<uint32_t *>(w + pl.a_counts_bytes + pl.a_records_bytes + pl.b_counts_bytes);
+    Arena arena;
+    arena.counts = reinterpret_cast<uint32_t *>(
+      w + pl.a_counts_bytes + pl.a_records_bytes + pl.b_counts_bytes + pl.b_records_bytes);
+    arena.records = reinterpret_cast<uint32_t *>(
+      w + pl.a_counts_bytes + pl.a_records_bytes + pl.b_counts_bytes + pl.b_records_bytes +
+      pl.arena_counts_bytes);
+    arena.n_buckets = pl.n_buckets;
+    arena.cap = pl.arena_cap;
+    if (pl.arena_cap == 0) {
+      arena.counts = nullptr;  // single-level table: no arena (see the top of the file)
+    } else if (hipMemsetAsync(arena.counts, 0, (size_t)L * pl.n_buckets * 4, s) != hipSuccess) {
+      return F2N_E_LAUNCH;
+    }
 
     BinArgs ba;
     ba.g_ld_point = g_ld_point;
@@ -1251,6 +1363,7 @@ extern "C" int f2n_hash_bwd_binned(
     ba.combine = combine;
     ba.stats = g_bin_stats.load(std::memory_order_relaxed);
     ba.overflow = g_overflow_counter.load(std::memory_order_relaxed);
+    ba.arena = arena;
     const int64_t tiles_g = tiles * pl.groups;
 #define F2N_BIN_LAUNCH(P2, SAT)                                                                     \
   hipLaunchKernelGGL(                                                                              \
@@ -1270,11 +1383,11 @@ extern "C" int f2n_hash_bwd_binned(
         if (disjoint)
           hipLaunchKernelGGL(
             (hash_bwd_reduce_kernel<FF, true>), grid_c, dim3(kBinBlock), 0, s, a_records, a_counts,
-            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g);
+            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g, arena);
         else
           hipLaunchKernelGGL(
             (hash_bwd_reduce_kernel<FF, false>), grid_c, dim3(kBinBlock), 0, s, a_records, a_counts,
-            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g);
+            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g, arena);
       } else {
         SplitArgs sa;
         sa.a_records = a_records;
@@ -1295,17 +1408,20 @@ extern "C" int f2n_hash_bwd_binned(
         sa.cap2 = pl.cap2;
         sa.stats = g_bin_stats.load(std::memory_order_relaxed);
         sa.overflow = ba.overflow;
+        sa.arena = arena;
         const dim3 grid_b((unsigned)pl.n_buckets, (unsigned)L, (unsigned)pl.n_parts);
         hipLaunchKernelGGL((hash_bwd_split_kernel<FF>), grid_b, dim3(kSplitBlock), 0, s, sa);
         const dim3 grid_c((unsigned)pl.n_slices, (unsigned)L);
         if (disjoint)
           hipLaunchKernelGGL(
             (hash_bwd_reduce_runs_kernel<FF, true>), grid_c, dim3(kBinBlock), 0, s, b_records,
-            b_counts, table_grad, T, level_stride, inv, pl.n_slices, pl.n_parts, pl.cap2);
+            b_counts, table_grad, T, level_stride, inv, pl.n_slices, pl.n_parts, pl.cap2,
+            pl.log2_sub, arena);
         else
           hipLaunchKernelGGL(
             (hash_bwd_reduce_runs_kernel<FF, false>), grid_c, dim3(kBinBlock), 0, s, b_records,
-            b_counts, table_grad, T, level_stride, inv, pl.n_slices, pl.n_parts, pl.cap2);
+            b_counts, table_grad, T, level_stride, inv, pl.n_slices, pl.n_parts, pl.cap2,
+            pl.log2_sub, arena);
       }
     })
 #undef F2N_BIN_LAUNCH

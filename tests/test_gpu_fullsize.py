@@ -212,10 +212,10 @@ def test_config_c5_full_batch_properties(capi, dev, field_c5):
     """2^22 points of config C5 (a quarter of its batch; 8.6 GB of encodings for the full 2^24 would
     only repeat this): the binned backward runs in several rounds over the points inside a 20 GiB
     workspace and must (a) agree with the scattered-atomic kernel, (b) conserve the gradient
-    (sum_d w_d = 1), (c) be bitwise reproducible (exact fixed-point sums) whenever the overflow
-    counter of f2n_hash_bwd_set_overflow_counter reads 0 -- records that found a queue or run full
-    are applied with float atomics and may differ in the last bits where two of them meet; their
-    number is bounded here and the affected entries stay within f16 resolution of each other."""
+    (sum_d w_d = 1), (c) be bitwise reproducible: exact fixed-point sums, with the records that find
+    a queue or run full (coarse levels: uniformly random points hit only ~36 000 distinct rows of
+    level 0, so some slices see several times the mean record count) summed exactly too, through the
+    overflow arena -- the counter of f2n_hash_bwd_set_overflow_counter must read 0."""
     f = field_c5
     L5, F5, T5 = C5["L"], C5["F"], 1 << C5["LOG2T"]
     st = T5 * F5
@@ -240,17 +240,9 @@ def test_config_c5_full_batch_properties(capi, dev, field_c5):
     finally:
         capi.lib().cdll.f2n_hash_bwd_set_overflow_counter(None)
     del ws
-    n_over = int(overflow.item())
+    assert int(overflow.item()) == 0                  # nothing was applied with a float atomic
+    assert torch.equal(outs[0], outs[1])              # exact sums: independent of summation order
     scale = float(outs[0].abs().max())
-    if n_over == 0:
-        assert torch.equal(outs[0], outs[1])          # exact sums: independent of summation order
-    else:
-        # records that overflowed into float atomics (coarse levels: uniformly random points hit only
-        # ~36 000 distinct rows of level 0, so some slices see several times the mean record count):
-        # few, and the entries they touch are order-dependent in their last bits only
-        assert n_over < 0.01 * 2 * n * L5 * 8, n_over
-        assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale
-        assert float((outs[0] != outs[1]).float().mean()) < 0.01
     with capi.option("HASH_BWD", 1):
         ta = torch.zeros(f["numel"], device=dev)
         capi.call("hash_bwd", x, f["table16"], f["primes"], f["bias"], f["mul"], g, 1, n, ta, None, n,

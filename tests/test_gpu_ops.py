@@ -216,6 +216,47 @@ def _ray_points(n_rays, S, seed):
     return torch.where(nrm <= 1, p, (2 - 1 / nrm) * p / nrm).contiguous()
 
 
+@pytest.mark.parametrize("L,F,log2_T,ws_frac", [(2, 8, 20, 1.0), (3, 8, 18, 0.5), (2, 2, 21, 1.0)])
+def test_hash_bwd_binned_overflow_stays_exact(capi, dev, L, F, log2_T, ws_frac):
+    """Two-level tables (more than 64 slices per level).  Skewed points (a tile's worth of them in
+    a tiny ball: eight rows carry all of their coarse levels' records) overflow the LDS queues of both
+    binning passes and the per-slice runs.  Those records go to the overflow arena of their (level,
+    bucket) and are summed exactly like the rest: the overflow counter stays 0 and two launches agree
+    BIT FOR BIT (a float-atomic fallback would make the last bits order-dependent)."""
+    T = 1 << log2_T
+    fld = util.make_field(L, F, log2_T, T * F, seed=9 + F)
+    st = fld["stride"]
+    n = 90000
+    pts = util.ball_points(n, seed=41)
+    pts[:1024] *= 0.004
+    g = torch.Generator().manual_seed(42)
+    grad = torch.randn(n, L * F, generator=g) * 1e-3           # every contribution non-zero
+    numel = fld["table"].numel()
+    ref_tg, _ = K.hash_bwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad,
+                           numel, L, F, T, st, 128.0, parallel=True)
+    need = capi.lib().cdll.f2n_hash_bwd_workspace_bytes(n, L, F, T)
+    nbytes = int(need * ws_frac) // 256 * 256
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d = _to(dev, pts, fld["primes"], fld["bias"], fld["mul"], grad)
+    overflow = torch.zeros(1, dtype=torch.int64, device=dev)
+    cd = capi.lib().cdll
+    assert cd.f2n_hash_bwd_set_overflow_counter(overflow.data_ptr()) == 0
+    outs = []
+    try:
+        for _ in range(2):
+            tg = torch.zeros(numel, device=dev)
+            capi.call("hash_bwd_binned", *d, L * F, 1, tg, n, L, F, T, st, 128.0, ws, nbytes)
+            outs.append(tg)
+        torch.cuda.synchronize()
+    finally:
+        cd.f2n_hash_bwd_set_overflow_counter(None)
+    assert int(overflow.item()) == 0
+    assert torch.equal(outs[0], outs[1])
+    scale = ref_tg.abs().max().item()
+    assert (outs[0].cpu() - ref_tg).abs().max().item() <= 2e-5 * scale
+    assert cd.f2n_hash_bwd_set_overflow_counter(3) != 0            # misaligned pointer: rejected
+
+
 @pytest.mark.parametrize("L,F,log2_T,S", [(16, 2, 19, 128), (8, 4, 16, 1024), (6, 1, 19, 256)])
 def test_hash_bwd_binned_combine(capi, dev, L, F, log2_T, S):
     """Ray-coherent points: coarse levels are combined per tile (sums leave as f16 pieces), fine

@@ -137,8 +137,14 @@ def main():
         if name == "current":
             capi.set_option("BWD_COMBINE", 0)
             stats = bin_stats.enable(lib, dev)
+            over = torch.zeros(1, dtype=torch.int64, device=dev)
+            lib.f2n_hash_bwd_set_overflow_counter.argtypes = [ctypes.c_void_p]
+            lib.f2n_hash_bwd_set_overflow_counter(over.data_ptr())
             run()
             bin_stats.report(lib, stats, L)
+            lib.f2n_hash_bwd_set_overflow_counter(None)
+            print("    records applied with float atomics (past queue, run AND arena): %d of %d"
+                  % (int(over.item()), n * L * 8))
         del ws
 
 
