@@ -110,6 +110,12 @@ def parse_args():
                          "(Renderer::render_image, VALIDATE mode, forward only; the reference's own "
                          "self-reported figure is seconds per rendered image, src/main_functions/"
                          "test.cpp:35-57) and report them as \"render_image\" -- not part of value")
+    ap.add_argument("--graph-iters", type=int, default=-1,
+                    help="after the headline measurement, capture ONE training batch of the reference's "
+                         "shape (device-side ray draw + TRAIN render + loss + backward, no host read: "
+                         "Renderer deferred_check) as a hipGraph and time K replays next to K eager "
+                         "batches; reported as \"graphed_batch\" -- not part of value.  Default: 200 for "
+                         "--workload c4, otherwise off")
     ap.add_argument("--train-iters", type=int, default=0,
                     help="after the headline measurement, time K complete data-parallel TRAINING "
                          "iterations of the reference's own shape (512 random rays per GPU drawn on the "
@@ -691,6 +697,68 @@ def time_hash_bwd_nonzero(args, pkg, H, ren, first_chunk, dev, reps=7):
                     "the C ABI, median of %d launches; not part of value" % (o.shape[0], reps)}
 
 
+def time_graphed_batches(args, H, dev, poses, intr, n_iter):
+    """The reference's training batch (confs/train_config.yaml:4: 512 rays drawn at random over all
+    images as src/dataset.cpp:150-171 does, here on the device; 1024 samples of 1/256; TRAIN render +
+    loss + backward) as ONE hipGraph: the Renderer runs without any host read (deferred_check: the
+    exact early-stop scan still runs, its verdict accumulates on the device and is read once, after
+    the loop), so the ~45 launches of a batch replay as one.  Eager batches of the same Renderer are
+    timed next to it."""
+    S = args.samples
+    ren = H.Renderer(args.n_images, n_levels=args.levels, n_channels=args.channels,
+                     log2_table=args.log2_table, max_samples=S, step=1.0 / 256 if S == 1024 else 4.0 / S)
+    with torch.no_grad():
+        ren.named_parameters()["scene_field.feat_pool"].normal_(0.0, 0.1)
+    ren.set_dense_first_pass(1)
+    n_rays = args.rays if args.rays > 0 else 512
+    images = torch.rand(args.n_images, 64, 64, 3, device=dev)   # stand-in ground truth, 64x64 per image
+    intr_small = intr.clone()
+    intr_small[:2] *= 64.0 / args.width
+    intr_all = intr_small[None].expand(args.n_images, 3, 3).contiguous()
+
+    def batch():
+        o, d, gt, cam = H.sample_random_rays(poses, intr_all, 64, 64, n_rays, images)
+        ren.zero_grad()
+        return ren.train_step(o, d, cam, gt, 0.0)
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    for _ in range(3):
+        batch()
+    ms_eager = timed(batch, n_iter)
+    ren.set_deferred_check(True)
+    ms_eager_deferred = timed(batch, n_iter)
+    out = {"rays_per_batch": n_rays, "samples_per_ray": S, "batches": n_iter, "ms_eager": ms_eager,
+           "ms_eager_no_host_read": ms_eager_deferred,
+           "note": "device-side ray draw + TRAIN render + loss + backward; not part of value"}
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):       # warm-up on a side stream, as graph capture requires
+            for _ in range(3):
+                batch()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            res = batch()
+        out["ms_graph"] = timed(g.replay, n_iter)
+        out["loss_after_replay"] = float(res[0])
+        out["rays_per_s_graph"] = n_rays / out["ms_graph"] * 1e3
+    except Exception as e:   # an extra: never a reason to lose the line
+        out["graph_error"] = repr(e)[:300]
+    torch.cuda.synchronize()
+    out["no_ray_terminated_early"] = bool(ren.deferred_check_ok())
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -791,13 +859,13 @@ def main():
     def run_step(view, timed=False):
         o, d, gt, emb = view
         ren.zero_grad()
-        sq = torch.zeros((), device=dev, dtype=torch.float64)
+        sq = None
         n_val = 0
         n_samples = 0
         for lo in range(0, n_rays_view, args.chunk):
             hi = min(lo + args.chunk, n_rays_view)
             loss, sq_err, nv, ns = ren.train_step(o[lo:hi], d[lo:hi], emb[lo:hi], gt[lo:hi], 0.0)
-            sq += sq_err.double()
+            sq = sq_err.double() if sq is None else sq + sq_err.double()
             n_val += nv
             n_samples += ns
         # the only collective of the path: {sum sq err, count} -> global PSNR (RCCL all-reduce), issued
@@ -919,6 +987,10 @@ def main():
                       "images": args.render_images,
                       "note": "%dx%d, %d samples/ray, VALIDATE (no jitter), forward only, one GPU; "
                               "not part of value" % (args.height, args.width, S)}
+    graphed = None
+    n_graph = args.graph_iters if args.graph_iters >= 0 else (200 if args.workload == "c4" else 0)
+    if n_graph > 0 and rank == 0:
+        graphed = time_graphed_batches(args, H, dev, poses, intr, n_graph)
     train_iter = None
     if args.train_iters > 0:
         train_iter = time_train_iterations(args, pkg, H, dev, dist if world > 1 else None, world, poses, intr)
@@ -1012,6 +1084,8 @@ def main():
         out.update(extras)
         if c5 is not None:
             out["c5"] = c5
+        if graphed is not None:
+            out["graphed_batch"] = graphed
         if train_iter is not None:
             out["train_iteration"] = train_iter
         if render_img is not None:

@@ -246,6 +246,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     .def("set_speculate_dense", [](Renderer & r, bool f) { r.options_.speculate_dense = f; })
     .def("set_pixel_tiles", [](Renderer & r, int b) { r.options_.pixel_tiles = b; })
     .def("set_margin_min_samples", [](Renderer & r, int64_t n) { r.options_.margin_min_samples = n; })
+    .def("set_deferred_check", [](Renderer & r, bool f) { r.options_.deferred_check = f; },
+         "no host read in render(): see RendererOptions::deferred_check")
+    .def("deferred_check_ok", &Renderer::deferred_check_ok)
     .def_readonly("last_kept_fraction", &Renderer::last_kept_fraction_)
     .def_readonly("last_n_samples", &Renderer::last_n_samples_)
     .def_property_readonly("scene_field", [](Renderer & r) { return r.scene_field_; })

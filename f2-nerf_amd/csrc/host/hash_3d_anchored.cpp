@@ -307,7 +307,11 @@ variable_list Hash3DAnchoredFunction::backward(AutogradContext * ctx, variable_l
   if (ws_bytes > 0 && field->options_.binned_backward) {
     size_t free_b = 0, total_b = 0;
     c10::hip::HIPGuard on_device(points.device().index());  // the query is about THIS tensor's device
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing((hipStream_t)stream, &capturing);
+    // (not while a hipGraph is being captured: the query is not a stream operation, and the capture's
+    // private pool serves the allocation below either way)
+    if (capturing == hipStreamCaptureStatusNone && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       // memory held by the caching allocator is reusable too: only cap when the device is tight
       const int64_t cap = (int64_t)(free_b / 2);
       if (cap < ws_bytes && cap >= ws_bytes / 16) ws_bytes = cap / 256 * 256;

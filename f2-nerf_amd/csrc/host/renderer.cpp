@@ -153,6 +153,33 @@ RenderResult Renderer::render_fused(
     //   Small chunks (the 512-ray training batch) keep the exact scan instead -- there it costs
     // 20 us, less than the GPU would idle while the host waits for a flag that only exists after
     // the shading pass -- and hide ITS read-back behind the same guess (further down).
+    if (options_.deferred_check && options_.fused_shade) {
+      // no host read: exact scan -> device-side "kept fewer than shaded" flag, all samples shaded
+      torch::NoGradGuard no_grad;
+      auto head = field.density_head();
+      Tensor counts = torch::empty({n_rays}, iopt);
+      {
+        f2n::ScopedKernelTimer timer("density_scan", stream, (double)n_rays);
+        f2n::check(
+          f2n_density_scan(
+            enc_all_cm.data_ptr<float>(), (int)C, all.dt.data_ptr<float>(),
+            head.first.data_ptr<float>(), head.second.data_ptr<float>(),
+            counts.data_ptr<int32_t>(), n_rays, S, options_.early_stop_trans, 3.f, stream),
+          "f2n_density_scan");
+      }
+      Tensor scratch_bounds = torch::empty({n_rays, 2}, iopt);
+      f2n::check(
+        f2n_bounds_from_counts(
+          counts.data_ptr<int32_t>(), scratch_bounds.data_ptr<int32_t>(), total.data_ptr<int32_t>(),
+          n_rays, stream),
+        "f2n_bounds_from_counts");
+      if (!deferred_bad_.defined()) deferred_bad_ = torch::zeros({1}, iopt);
+      deferred_bad_.add_(total.ne(n_all).to(torch::kInt32));
+      last_n_samples_ = n_all;
+      last_kept_fraction_ = 1.f;
+    }
+    if (options_.deferred_check && options_.fused_shade)
+      return shade_and_composite(all, emb_idx, mode, bg_color, enc_all_cm, contracted_all);
     const bool may_guess = options_.speculate_dense && last_kept_fraction_ >= 1.f && n_all > 0;
     const int64_t kMarginMinSamples = options_.margin_min_samples;
     if (may_guess && n_all >= kMarginMinSamples) {
@@ -273,6 +300,14 @@ RenderResult Renderer::render_fused(
       "f2n_sample_compact");
   }
   return shade_and_composite(kept, emb_idx, mode, bg_color);
+}
+
+bool Renderer::deferred_check_ok()
+{
+  if (!deferred_bad_.defined()) return true;
+  const bool ok = deferred_bad_.item<int32_t>() == 0;  // the caller's sync point
+  deferred_bad_.zero_();
+  return ok;
 }
 
 // Second pass on the survivors (renderer.cpp:92-118).

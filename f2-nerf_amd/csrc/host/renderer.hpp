@@ -74,6 +74,15 @@ struct RendererOptions
   // ... chunks of at least this many samples accept the guess on the density-margin flag (no exact
   // scan at all), smaller ones run the scan and only hide its read-back behind the guess
   int64_t margin_min_samples = 2 << 20;
+  // No host read at all (what a hipGraph capture of a training iteration needs; the reference
+  // syncs at src/renderer.cpp:39-40,69,85-87,120): the dense first pass shades ALL samples and
+  // returns that as the result without waiting for the survivor count; whether a ray would have
+  // terminated early is ACCUMULATED on the device instead (deferred_bad_: += 1 for every render whose
+  // exact scan kept fewer samples than it shaded) and the caller asks deferred_check_ok() whenever it
+  // next synchronises anyway -- before it lets an optimiser consume the gradients.  A render whose
+  // check fails produced colours that include samples the reference would have dropped (their
+  // weights are below 1e-4 of the ray's, but not zero) and must be repeated without this option.
+  bool deferred_check = false;
   bool check_finite = false;       // the reference's CHECK(isfinite(colors.mean())) host sync
 };
 
@@ -111,6 +120,12 @@ public:
   int64_t last_n_samples_ = 0;  // survivors of the most recent render() (bench bookkeeping)
   float last_kept_fraction_ = 0.f;
   f2n::HostCount survivors_;
+
+  // options_.deferred_check: renders since the last reset whose guess "nothing terminates" was wrong
+  // (device int32, created on first use; stays valid across hipGraph replays).  deferred_check_ok()
+  // reads it (a host sync) and resets it.
+  Tensor deferred_bad_;
+  bool deferred_check_ok();
 
 private:
   RenderResult render_fused(

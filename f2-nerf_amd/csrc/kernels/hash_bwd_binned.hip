@@ -231,7 +231,9 @@ __device__ __forceinline__ void load_record(const uint32_t * base, int cap, uint
 
 // Copy the first `cnt` records of an LDS queue (capacity src_cap) into a workspace region (capacity
 // dst_cap, records dst_off..) with the 64 lanes of one wave.
-template <int F>
+// ROWS4: the caller owns the whole destination region and appends nothing behind these records (pass
+// A's flush), so the row array may be copied in whole uint4s.
+template <int F, bool ROWS4 = false>
 __device__ __forceinline__ void copy_records(
   const uint32_t * src, int src_cap, uint32_t * dst, int dst_cap, uint32_t dst_off, uint32_t cnt, int lane)
 {
@@ -241,7 +243,16 @@ __device__ __forceinline__ void copy_records(
     uint2 * d = reinterpret_cast<uint2 *>(dst) + dst_off;
     for (uint32_t i = lane; i < cnt; i += 64) d[i] = s[i];
   } else {
-    for (uint32_t i = lane; i < cnt; i += 64) dst[dst_off + i] = src[i];
+    if (ROWS4 && (dst_off & 3u) == 0u) {
+      // rows four at a time (queue and region capacities are multiples of four records, so the whole
+      // uint4 that holds the last row exists on both sides): a 4-byte store per lane moves 256 bytes
+      // per instruction, a fifth of the record bytes but half of the flush's store instructions
+      const uint4 * s4 = reinterpret_cast<const uint4 *>(src);
+      uint4 * d4 = reinterpret_cast<uint4 *>(dst + dst_off);
+      for (uint32_t i = lane; i < (cnt + 3u) / 4u; i += 64) d4[i] = s4[i];
+    } else {
+      for (uint32_t i = lane; i < cnt; i += 64) dst[dst_off + i] = src[i];
+    }
     if constexpr (VW == 2) {
       const uint2 * s = reinterpret_cast<const uint2 *>(src + src_cap);
       uint2 * d = reinterpret_cast<uint2 *>(dst + dst_cap) + dst_off;
@@ -525,7 +536,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       } else {
         for (int b = wave; b < a.n_buckets; b += kWaves) {
           const uint32_t cnt = min(qcount[b], (uint32_t)cap);
-          copy_records<F>(
+          copy_records<F, true>(
             queue + (size_t)b * cap * KW, cap, region0 + (size_t)b * a.qcap * KW, a.qcap, 0u, cnt, lane);
         }
       }

@@ -34,13 +34,13 @@ bench() {  # bench NAME args
 case $what in
   c2)
     bench bench_c2 --steps 20 --warmup 5
-    prof c2_stats stats -- --steps 6 --warmup 2 --no-cpu-baseline
-    prof pmc_fetch_c2 pmc FETCH_SIZE -- --steps 2 --warmup 1 --no-cpu-baseline
-    prof pmc_write_c2 pmc WRITE_SIZE -- --steps 2 --warmup 1 --no-cpu-baseline
+    prof c2_stats stats -- --steps 6 --warmup 2 --no-cpu-baseline --no-extras
+    prof pmc_fetch_c2 pmc FETCH_SIZE -- --steps 2 --warmup 1 --no-cpu-baseline --no-extras
+    prof pmc_write_c2 pmc WRITE_SIZE -- --steps 2 --warmup 1 --no-cpu-baseline --no-extras
     ;;
   c4c5)
-    bench bench_c4 --rays 512 --samples 1024 --steps 50 --warmup 10 --no-cpu-baseline --train-iters 50
-    prof c4_stats stats -- --rays 512 --samples 1024 --steps 50 --warmup 10 --no-cpu-baseline
+    bench bench_c4 --workload c4 --steps 50 --warmup 10 --no-cpu-baseline --train-iters 50
+    prof c4_stats stats -- --workload c4 --steps 50 --warmup 10 --no-cpu-baseline --graph-iters 0
     bench bench_c5 --workload c5 --steps 3 --warmup 1
     prof c5_stats stats -- --workload c5 --steps 2 --warmup 1 --no-cpu-baseline
     prof pmc_fetch_c5 pmc FETCH_SIZE -- --workload c5 --steps 1 --warmup 1 --no-cpu-baseline
@@ -54,7 +54,8 @@ case $what in
     bench bench_c2_term --steps 10 --warmup 3 --no-cpu-baseline --regime terminating
     bench bench_c1_shape --levels 4 --samples 64 --steps 10 --warmup 3 --no-cpu-baseline
     bench bench_c1_chunk8192 --levels 4 --samples 64 --chunk 8192 --steps 5 --warmup 2 --no-cpu-baseline
-    bench bench_c3 --height 1080 --width 1920 --samples 192 --steps 5 --warmup 2 --no-cpu-baseline
+    bench bench_c3 --workload c3 --steps 5 --warmup 2 --no-cpu-baseline
+    bench bench_c2_tiles --pixel-tiles 8 --steps 10 --warmup 3 --no-cpu-baseline --no-extras
     bench bench_inference --steps 3 --warmup 1 --no-cpu-baseline --render-images 10
     bench bench_2rank_gloo_shared --gpus 2 --backend gloo --share-gpu --steps 3 --warmup 1 --no-cpu-baseline
     ;;
