@@ -678,6 +678,9 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
           if (threadIdx.x < kMaxBuckets) qcount[threadIdx.x] = 0u;
           __syncthreads();
         }
+        // (the tile's POINTS take turns; letting its corners take turns instead -- every thread busy
+        // in every round, the hash computed once per round -- was measured and lost: 59.8 vs 58.1 ms
+        // per 2^24 points of config C5)
         if (active && (int)((threadIdx.x * (unsigned)a.groups) / kBinBlock) == g) {
           const LevelParams lp = load_level(primes, bias, mul, l);
           corner_rows_and_weights<POW2>(x, y, z, lp, a.T, row, w);
@@ -1130,25 +1133,52 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_runs_kernel(
   const int sidx = blockIdx.x, l = blockIdx.y;
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
+  const uint32_t row_lo = (uint32_t)sidx * kRows;
+  float * gbase_slice = table_grad + level_stride * l + (int64_t)row_lo * F;
+  auto run_of = [&](int part, uint32_t & cnt) {
+    const size_t ridx = ((size_t)l * n_slices + sidx) * n_parts + part;
+    cnt = min(b_counts[ridx], (uint32_t)cap2);
+    return b_records + ridx * (size_t)cap2 * KW;
+  };
+  auto load_chunk = [&](const uint32_t * run, uint32_t cnt, uint32_t i0, uint32_t (&r)[kUnroll],
+                        uint32_t (&v)[kUnroll][VW]) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++)
+      load_record<F>(run, cap2, min(i0 + 64 * u + lane, cnt - 1u), r[u], v[u]);  // tail lanes re-read
+  };
+  auto add_chunk = [&](uint32_t cnt, uint32_t i0, const uint32_t (&r)[kUnroll],
+                       const uint32_t (&v)[kUnroll][VW]) {
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++)
+      if (i0 + 64 * u + lane < cnt) accumulate_record<F>(acc, r[u], v[u]);
+  };
+  // One workgroup per CU (137 KiB of sums) and ~130 of them in a row per CU: the count and the
+  // first records of this wave's first run are requested BEFORE the sums are zeroed, so that the two
+  // dependent memory latencies do not sit behind the barrier of every slice.
+  uint32_t r0[kUnroll], v0[kUnroll][VW], cnt0 = 0u;
+  const uint32_t * run0 = nullptr;
+  if (wave < n_parts) {
+    run0 = run_of(wave, cnt0);
+    if (cnt0) load_chunk(run0, cnt0, 0u, r0, v0);
+  }
   zero_slice(acc);
   __syncthreads();
 
-  const uint32_t row_lo = (uint32_t)sidx * kRows;
-  float * gbase_slice = table_grad + level_stride * l + (int64_t)row_lo * F;
-  for (int part = wave; part < n_parts; part += kWaves) {
-    const size_t ridx = ((size_t)l * n_slices + sidx) * n_parts + part;
-    const uint32_t cnt = min(b_counts[ridx], (uint32_t)cap2);
-    const uint32_t * run = b_records + ridx * (size_t)cap2 * KW;
+  if (cnt0) {
+    add_chunk(cnt0, 0u, r0, v0);
+    for (uint32_t i0 = 64 * kUnroll; i0 < cnt0; i0 += 64 * kUnroll) {
+      uint32_t r[kUnroll], v[kUnroll][VW];
+      load_chunk(run0, cnt0, i0, r, v);
+      add_chunk(cnt0, i0, r, v);
+    }
+  }
+  for (int part = wave + kWaves; part < n_parts; part += kWaves) {
+    uint32_t cnt;
+    const uint32_t * run = run_of(part, cnt);
     for (uint32_t i0 = 0; i0 < cnt; i0 += 64 * kUnroll) {
       uint32_t r[kUnroll], v[kUnroll][VW];
-#pragma unroll
-      for (int u = 0; u < kUnroll; u++) {
-        const uint32_t i = min(i0 + 64 * u + lane, cnt - 1u);
-        load_record<F>(run, cap2, i, r[u], v[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < kUnroll; u++)
-        if (i0 + 64 * u + lane < cnt) accumulate_record<F>(acc, r[u], v[u]);
+      load_chunk(run, cnt, i0, r, v);
+      add_chunk(cnt, i0, r, v);
     }
   }
   accumulate_arena<F>(

@@ -255,6 +255,11 @@ def test_hash_bwd_binned_overflow_stays_exact(capi, dev, L, F, log2_T, ws_frac):
     scale = ref_tg.abs().max().item()
     assert (outs[0].cpu() - ref_tg).abs().max().item() <= 2e-5 * scale
     assert cd.f2n_hash_bwd_set_overflow_counter(3) != 0            # misaligned pointer: rejected
+    # another record order (the per-tile combine off), same exact sums
+    with capi.option("BWD_COMBINE", 1):
+        tg = torch.zeros(numel, device=dev)
+        capi.call("hash_bwd_binned", *d, L * F, 1, tg, n, L, F, T, st, 128.0, ws, nbytes)
+    assert torch.equal(tg, outs[0])
 
 
 @pytest.mark.parametrize("L,F,log2_T,S", [(16, 2, 19, 128), (8, 4, 16, 1024), (6, 1, 19, 256)])

@@ -207,6 +207,62 @@ def test_dense_pass_guess_changes_nothing(host, dev, margin_path):
     same(step_once(True), ref_term)
 
 
+def test_deferred_check_renders_without_a_host_read_and_graphs(host, dev):
+    """RendererOptions::deferred_check: the dense first pass returns the all-samples shading without
+    reading the survivor count; the verdict of the exact scan accumulates on the device.  Thin
+    medium: same pixels and gradients as the checked path, verdict ok, and the whole training batch
+    (render + loss + backward) can be captured as one hipGraph whose replay reproduces the eager
+    result.  Opaque medium: the verdict says the guess was wrong (the caller must redo that batch)."""
+    L, F, log2_T, S, step = 4, 2, 14, 64, 4.0 / 64
+    oracle, hr, o, d, noise, bg, gt, emb = _setup(host, L, F, log2_T, S, step, 96, -3.0, 33)
+    to = lambda x: x.to(dev)
+    hr.set_fused(True)
+    hr.set_fused_shade(True)
+    hr.set_dense_first_pass(1)
+    args = (to(o), to(d), to(emb), to(gt), 1e-2, to(noise), to(bg), True)
+
+    def batch():
+        hr.zero_grad()
+        loss, sq, nv, ns = hr.train_step(*args)
+        return loss, sq
+
+    loss_ref, sq_ref = batch()
+    grads_ref = {k: v.clone() for k, v in hr.grads().items() if v is not None}
+    hr.set_deferred_check(True)
+    loss_def, sq_def = batch()
+    assert hr.deferred_check_ok()
+    assert torch.equal(loss_def, loss_ref) and torch.equal(sq_def, sq_ref)
+    # one hipGraph for the batch (warm-up on a side stream first, as capture requires)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            batch()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        loss_g, sq_g = batch()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(loss_g, loss_ref) and torch.equal(sq_g, sq_ref)
+    for k, want in grads_ref.items():      # (sums by float atomics: equal up to their order)
+        got = hr.grads()[k]
+        scale = float(want.abs().max())
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5 * scale + 1e-30)
+    assert hr.deferred_check_ok()
+    # opaque medium: rays terminate, the all-samples shading is NOT the reference's result
+    with torch.no_grad():
+        hr.named_parameters()["scene_field.mlp.bias"][0] = 8.0
+    batch()
+    assert not hr.deferred_check_ok()
+    assert hr.deferred_check_ok()          # the verdict is reset by reading it
+    hr.set_deferred_check(False)
+    batch()
+    assert hr.last_kept_fraction < 0.9
+
+
 def test_config_c3_view_chunk_properties(host, dev):
     """BASELINE config C3 at its own size: one 1920 x 1080 free-trajectory view, 192 samples per ray.
     The oracle needs minutes at this size, so the full-width chunk is checked through properties:

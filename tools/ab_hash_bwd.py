@@ -68,10 +68,16 @@ def main():
     ap.add_argument("--zero-rays", type=float, default=0.0, help="fraction of rays whose gradient is zero")
     ap.add_argument("--grad-scale", type=float, default=1e-3, help="std of the synthetic gradient")
     ap.add_argument("--levels", type=int, default=0, help="override L")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="kernel route (f2n_set_option) for the 'current' library, e.g. BIN_SPLIT=1")
     ap.add_argument("--other", action="append", default=[], metavar="NAME",
                     help="also time tools/ab/libf2nerf_hip_NAME.so (an experimental build)")
     args = ap.parse_args()
     capi = importlib.import_module("f2-nerf_amd").capi
+    for kv in args.option:
+        k, v = kv.split("=")
+        capi.set_option(k, int(v))
+        print("option %s = %s" % (k, v))
     dev = torch.device("cuda:0")
     # (L, F, log2_T, disjoint stride, n_rays, S)
     cfg = {"c2": (16, 2, 19, False, 65536, 128), "c4": (16, 2, 19, False, 512, 1024),
