@@ -1039,15 +1039,23 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
   const int sidx = blockIdx.x, l = blockIdx.y;
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
-  zero_slice(acc);
-  if (threadIdx.x < kWaves) batch_off[threadIdx.x][64] = 0xffffffffu;  // sentinel for the search
-  __syncthreads();
-
   const uint32_t row_lo = (uint32_t)sidx * kRows;
   float * gbase_slice = table_grad + level_stride * l + (int64_t)row_lo * F;
   const uint32_t * counts = ws_counts + ((size_t)l * n_slices + sidx) * n_tiles;
   const size_t tile_stride = (size_t)n_slices * qcap * KW;  // words between tiles, same slice
   const uint32_t * base = ws_records + ((size_t)l * n_tiles * n_slices + sidx) * (size_t)qcap * KW;
+  // (fewer tiles per batch when there are few tiles -- a 512-ray training batch has 512 -- so that
+  // all sixteen waves have one)
+  int bt = 64;
+  while (bt > 8 && (int64_t)bt * kWaves > n_tiles) bt >>= 1;
+  // the counts of this wave's first batch are requested before the sums are zeroed: one memory
+  // latency less behind the barrier of each of the ~1000 workgroups
+  const int64_t t_first = (int64_t)wave * bt;
+  const uint32_t first_cnt = (lane < bt && t_first + lane < n_tiles) ? counts[t_first + lane] : 0u;
+  zero_slice(acc);
+  if (threadIdx.x < kWaves) batch_off[threadIdx.x][64] = 0xffffffffu;  // sentinel for the search
+  __syncthreads();
+
   // A wave owns 64 consecutive tiles at a time.  One coalesced load fetches their counts; their
   // records are then walked as ONE flat list (lane f handles the f-th record of the batch, found by
   // a binary search over the scanned counts kept in LDS), so every load instruction has 64 busy
@@ -1055,13 +1063,10 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
   // gradients) cost no more than their records.
   uint32_t * woff = &batch_off[wave][0];
   constexpr int kFlat = 16;  // 64-record loads in flight per wave
-  // (fewer tiles per batch when there are few tiles -- a 512-ray training batch has 512 -- so that
-  // all sixteen waves have one)
-  int bt = 64;
-  while (bt > 8 && (int64_t)bt * kWaves > n_tiles) bt >>= 1;
-  for (int64_t t0 = (int64_t)wave * bt; t0 < n_tiles; t0 += (int64_t)kWaves * bt) {
-    const uint32_t my_cnt =
-      (lane < bt && t0 + lane < n_tiles) ? min(counts[t0 + lane], (uint32_t)qcap) : 0u;
+  for (int64_t t0 = t_first; t0 < n_tiles; t0 += (int64_t)kWaves * bt) {
+    const uint32_t asked =
+      (t0 == t_first) ? first_cnt : ((lane < bt && t0 + lane < n_tiles) ? counts[t0 + lane] : 0u);
+    const uint32_t my_cnt = min(asked, (uint32_t)qcap);
     const uint32_t incl = (uint32_t)wave_incl_scan_i32((int)my_cnt);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     if (total > 64u * 40u) {
@@ -1161,6 +1166,9 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_runs_kernel(
     run0 = run_of(wave, cnt0);
     if (cnt0) load_chunk(run0, cnt0, 0u, r0, v0);
   }
+  // (reading the slice's current gradient values here as well, so that the flush ends in plain
+  // stores, was measured and bought nothing: 61.4 vs 61.2 ms per 2^24 points of config C5; sixteen
+  // 64-record loads in flight per wave instead of eight: 67 ms)
   zero_slice(acc);
   __syncthreads();
 
