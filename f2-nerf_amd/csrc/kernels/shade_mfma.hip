@@ -499,7 +499,9 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
 
     // ---- the next stride's inputs (their registers are free since the head layer / the SH block;
     // issued behind the vector phases and the d w1 product, which leave no registers for them: the
-    // 128 products of the last three phases, ~4 K cycles, cover the latency)
+    // 128 products of the last three phases, ~4 K cycles, cover the latency -- asking one phase
+    // earlier, 260 products ahead, measured the same within noise, 1.45-1.50 ms, and spills the WIDE
+    // instantiation)
     load_inputs(st + wave_count, eB, img, dir);
     issue_fence();
 
@@ -674,9 +676,9 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
 // The forward third of the kernel above (head, hidden and output layer in the Q-layout, no lane
 // movement), three waves per SIMD: no accumulators live across strides and the other waves hide one
 // wave's loads.  The output layer STAYS on the matrix cores here (rows 0, 4, 8 of a 16-row operand):
-// the vector form the backward uses was measured and lost, 0.64 ms (0.62 at two waves per SIMD)
-// against 0.55 per 8.4 M samples -- 52 products fewer but 200 vector instructions more and, at 168
-// registers, spills; this kernel waits on latencies, not on the matrix pipe.  LDS: the three forward weight operands (56 slots at
+// the vector form the backward uses was measured here too and lost, 0.58 against 0.55 ms per 8.2 M
+// samples inside the bench -- 52 products fewer but 200 vector instructions more and, at 168
+// registers, ten spilled; this kernel waits on latencies, not on the matrix pipe.  LDS: the three forward weight operands (56 slots at
 // C = 32) + a 16-row tile per wave that moves SH16(dir) from lane = sample into the Q-layout.
 template <int C, int W = 12>
 struct FShape

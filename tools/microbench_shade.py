@@ -6,6 +6,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 capi = importlib.import_module("f2-nerf_amd").capi
+if len(sys.argv) > 2 and sys.argv[1] == "--lib":      # an experimental build instead of lib/libf2nerf_hip.so
+    capi.LIB_PATH = os.path.abspath(sys.argv[2])
+    print("library:", capi.LIB_PATH)
 dev = torch.device("cuda:0")
 n, C, E = 65536 * 128, 32, 50
 g = torch.Generator(device=dev).manual_seed(0)
