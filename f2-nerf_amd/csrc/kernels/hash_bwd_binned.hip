@@ -447,9 +447,16 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       if (slot < (uint32_t)cap)
         // (bucket < 64, cap * KW <= 32768: a 24-bit multiply is full rate, v_mul_lo_u32 a quarter)
         store_record<F>(queue + __umul24(bucket, (uint32_t)(cap * KW)), cap, slot, r & bmask, val);
-      else if (!arena_push<F>(a.arena, l, bucket, (r & bmask) / kSliceRows, (r & bmask) % kSliceRows, val)) {
-        apply_record_atomic<F>(gbase, r, val, a.inv_scale);
-        if (a.overflow) atomicAdd(a.overflow, 1ull);
+      else {
+        // (SAT = a two-level table: only those keep an arena; the single-level kernel does not even
+        // carry the code -- with it, the bench's sparse regime measured 2 % slower)
+        bool kept = false;
+        if constexpr (SAT)
+          kept = arena_push<F>(a.arena, l, bucket, (r & bmask) / kSliceRows, (r & bmask) % kSliceRows, val);
+        if (!kept) {
+          apply_record_atomic<F>(gbase, r, val, a.inv_scale);
+          if (a.overflow) atomicAdd(a.overflow, 1ull);
+        }
       }
     };
     // wave w copies the queues of buckets w, w+16, ... to their workspace regions and records the
@@ -1029,7 +1036,7 @@ template <int F, bool DISJOINT>
 __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
   const uint32_t * __restrict__ ws_records, const uint32_t * __restrict__ ws_counts,
   float * __restrict__ table_grad, uint32_t T, int64_t level_stride, float inv_scale, int n_slices,
-  int qcap, int64_t n_tiles, const Arena arena)
+  int qcap, int64_t n_tiles)
 {
   constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
   constexpr uint32_t kRows = kBinAcc / F;
@@ -1118,7 +1125,6 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
         if (f0 + 64u * u + lane < total) accumulate_record<F>(acc, r[u], v[u]);
     }
   }
-  accumulate_arena<F>(acc, arena, l, (uint32_t)sidx, 0u);
   __syncthreads();
   flush_slice<F, DISJOINT>(acc, gbase_slice, row_lo, T, inv_scale);
 }
@@ -1432,11 +1438,11 @@ extern "C" int f2n_hash_bwd_binned(
         if (disjoint)
           hipLaunchKernelGGL(
             (hash_bwd_reduce_kernel<FF, true>), grid_c, dim3(kBinBlock), 0, s, a_records, a_counts,
-            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g, arena);
+            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g);
         else
           hipLaunchKernelGGL(
             (hash_bwd_reduce_kernel<FF, false>), grid_c, dim3(kBinBlock), 0, s, a_records, a_counts,
-            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g, arena);
+            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g);
       } else {
         SplitArgs sa;
         sa.a_records = a_records;
