@@ -299,7 +299,7 @@ variable_list Hash3DAnchoredFunction::backward(AutogradContext * ctx, variable_l
   // Large training batches: bin the contributions by table slice into a scratch workspace and
   // reduce them in LDS (no scattered atomics; exact, order-independent sums).  The recommended
   // workspace is about 3 bytes per algorithmic byte (16 GiB for 8.4 M samples at L = 16, F = 2,
-  // capped at 48 GiB: bigger batches run in rounds); it is further capped at half of the device's
+  // capped at 64 GiB: bigger batches run in rounds); it is further capped at half of the device's
   // free memory, and when even that cannot be allocated the atomic kernel takes over.
   int64_t ws_bytes =
     want_points ? 0 : f2n_hash_bwd_workspace_bytes(n, L, F, (uint32_t)field->local_size_);

@@ -23,14 +23,14 @@
 //                    then add the slice into the table gradient with contiguous float atomics (the
 //                    reference's level windows overlap, quirk Q2, so it must be an add).
 //
-// Capacities never affect results.  Two-level tables: a record that finds its queue, region or run
-// full goes to the ARENA of its (level, bucket) -- an append buffer in the workspace that the reduce
-// pass of every slice of that bucket scans after its own runs -- and is summed exactly like the rest;
-// only a record that finds the arena full as well is applied directly with a global float atomic.
-// Single-level tables apply a record that finds its queue full directly (measured: routing those
-// through an arena costs 1 ms per 8.4 M dense samples whose coarse levels overflow by design, and up
-// to 3 ms on a camera's adjacent pixels; their float atomics spread over the table).  A direct add
-// is order-dependent in the last bit, like the reference's own atomics, and counted
+// Capacities never affect results.  Pass B (two-level tables): a record that finds its sub-slice
+// queue or its run full goes to the ARENA of its (level, bucket) -- an append buffer in the workspace
+// that the reduce pass of every slice of that bucket scans after its own runs -- and is summed exactly
+// like the rest; only a record that finds the arena full as well is applied directly with a global
+// float atomic.  Pass A applies a record that finds its LDS queue full directly: a tile whose points
+// pile onto a few rows (the per-tile combine exists for those; measured: routing them through the
+// arena costs 1-3 ms per 8.4 M dense samples on single-level tables and 9 % of pass A on config C5).
+// A direct add is order-dependent in the last bit, like the reference's own atomics, and counted
 // (f2n_hash_bwd_set_overflow_counter).
 #include "hash_grid.hiph"
 
@@ -42,10 +42,13 @@ namespace
 
 constexpr int kBinBlock = 1024;        // threads = points per tile (pass A), threads of pass C
 constexpr int kBinAcc = 16384;         // 64-bit accumulators per slice (128 KiB)
-constexpr int kBinQueueWords = 32768;  // 128 KiB of LDS record staging per tile (pass A)
+// LDS record staging per tile (pass A): 156 KiB, all a CU has next to the counters.  F = 8 with 64
+// buckets: 124 records per queue for a mean of 64 per round, 7.5 sigma of an even spread -- at
+// 32768 words (100 records, 4.5 sigma) config C5 sent ~2000 of its 2.1e9 records past a full queue.
+constexpr int kBinQueueWords = 39936;
 constexpr int kCombAccWords = 8192 + 16;  // combine mode: 4096 (+ pitch padding) 64-bit sums, M = 4096 / F slots
 constexpr int kCombTagWords = 4096;    //               M row tags (sized for F = 1)
-constexpr int kCombQueueWords = kBinQueueWords - kCombAccWords - kCombTagWords;  // 80 KiB stay a queue
+constexpr int kCombQueueWords = kBinQueueWords - kCombAccWords - kCombTagWords;  // 108 KiB stay a queue
 constexpr int kMaxPieces = 6;          // f16 pieces per combined sum before the remainder goes atomic
 // A combined level costs about twice a plain one (two ds_add_u64 per contribution, 4-way same-address
 // inside a wave at the coarsest levels), so it must shrink the record stream a lot to pay:
@@ -281,7 +284,6 @@ struct BinArgs
   int n_buckets, bshift, groups, qcap, qcap_comb, combine;
   uint32_t * stats;  // optional [L][4] u32 counters (tools/ab_hash_bwd.py), else NULL
   unsigned long long * overflow;  // optional: += records applied with float atomics, else NULL
-  Arena arena;
 };
 
 // SAT: sum the saturated cell (0,0,0) in LDS (tables that take the split pass); a template
@@ -295,7 +297,6 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
 {
   constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
   constexpr uint32_t kSlots = 4096 / F;  // combine table: slots (tags), F 64-bit sums each
-  constexpr uint32_t kSliceRows = kBinAcc / F;  // rows of one reduce-pass slice
   // channel-major with an odd pitch, for the same bank reason as SliceAcc (F >= 2: 4096 + F words)
   auto comb_index = [](uint32_t slot, int k) { return (uint32_t)k * (kSlots + (F > 1 ? 1u : 0u)) + slot; };
   __shared__ __attribute__((aligned(16))) uint32_t queue[kBinQueueWords];
@@ -448,15 +449,11 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
         // (bucket < 64, cap * KW <= 32768: a 24-bit multiply is full rate, v_mul_lo_u32 a quarter)
         store_record<F>(queue + __umul24(bucket, (uint32_t)(cap * KW)), cap, slot, r & bmask, val);
       else {
-        // (SAT = a two-level table: only those keep an arena; the single-level kernel does not even
-        // carry the code -- with it, the bench's sparse regime measured 2 % slower)
-        bool kept = false;
-        if constexpr (SAT)
-          kept = arena_push<F>(a.arena, l, bucket, (r & bmask) / kSliceRows, (r & bmask) % kSliceRows, val);
-        if (!kept) {
-          apply_record_atomic<F>(gbase, r, val, a.inv_scale);
-          if (a.overflow) atomicAdd(a.overflow, 1ull);
-        }
+        // (not to the overflow arena: its code at the eight corners cost the two-level kernel 17
+        // spilled registers and 9 % of its time, and the single-level kernel 2 %; instead the queues
+        // are large enough that evenly spread points never get here, see kBinQueueWords)
+        apply_record_atomic<F>(gbase, r, val, a.inv_scale);
+        if (a.overflow) atomicAdd(a.overflow, 1ull);
       }
     };
     // wave w copies the queues of buckets w, w+16, ... to their workspace regions and records the
@@ -1306,7 +1303,7 @@ BinPlan bin_plan(int64_t n, int L, int F, uint32_t T, int64_t workspace_bytes)
   return pl;
 }
 
-constexpr int64_t kRecommendedWorkspaceCap = (int64_t)48 << 30;
+constexpr int64_t kRecommendedWorkspaceCap = (int64_t)64 << 30;
 
 std::atomic<uint32_t *> g_bin_stats{nullptr};
 std::atomic<unsigned long long *> g_overflow_counter{nullptr};
@@ -1418,7 +1415,6 @@ extern "C" int f2n_hash_bwd_binned(
     ba.combine = combine;
     ba.stats = g_bin_stats.load(std::memory_order_relaxed);
     ba.overflow = g_overflow_counter.load(std::memory_order_relaxed);
-    ba.arena = arena;
     const int64_t tiles_g = tiles * pl.groups;
 #define F2N_BIN_LAUNCH(P2, SAT)                                                                     \
   hipLaunchKernelGGL(                                                                              \

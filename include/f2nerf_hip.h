@@ -116,7 +116,7 @@ int f2n_hash_bwd(
  * Tables with more than 64 LDS-sized slices per level (T*F > 2^20, e.g. T = 2^22, F = 8) take a
  * second binning pass; coarse levels whose cells are shared by the points of a tile are combined
  * before they are binned (F2N_OPT_BWD_COMBINE).
- * f2n_hash_bwd_workspace_bytes returns the recommended workspace size (at most 48 GiB), or 0 when
+ * f2n_hash_bwd_workspace_bytes returns the recommended workspace size (at most 64 GiB), or 0 when
  * the binned path does not apply to (n, L, F, T): n < 65536 or T*F > 2^26 -- use f2n_hash_bwd then.
  * workspace: device memory, 256-byte aligned, contents undefined on entry and exit.  A smaller
  * workspace makes the passes run in several rounds over the points (same results);

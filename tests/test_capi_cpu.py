@@ -28,6 +28,22 @@ def test_header_symbols_all_exported(capi):
     assert lib.status_string(0) == "ok" and "invalid" in lib.status_string(-1)
 
 
+def test_documented_workspace_cap_is_the_real_one(capi):
+    """the ABI header's "at most N GiB" for f2n_hash_bwd_workspace_bytes must be the cap
+    the library applies (an integrator budgets memory from the header).  A host-side planning call:
+    no kernel runs."""
+    text = open(capi.HEADER).read()
+    m = re.search(r"recommended workspace size \(at most (\d+) GiB\)", text)
+    assert m, "the header must state the cap"
+    cap = int(m.group(1)) << 30
+    fn = capi.lib().cdll.f2n_hash_bwd_workspace_bytes
+    huge = fn(1 << 28, 16, 8, 1 << 22)          # far more than one round's worth: capped
+    assert 0.8 * cap <= huge <= cap + 4096
+    small = fn(1 << 17, 16, 2, 1 << 19)
+    assert 0 < small < cap // 16
+    assert fn(1000, 16, 2, 1 << 19) == 0         # below 65536 points: not applicable
+
+
 def test_header_cites_reference_for_every_entry_point(capi):
     text = open(capi.HEADER).read()
     for name in capi.parse_header():

@@ -224,7 +224,7 @@ def test_config_c5_full_batch_properties(capi, dev, field_c5):
     x = _ball(n, dev, f["g"])
     g = torch.randn(C5c, n, device=dev, generator=f["g"]) * 1e-3
     need = capi.lib().cdll.f2n_hash_bwd_workspace_bytes(n, L5, F5, T5)
-    assert 0 < need <= (48 << 30) + 4096
+    assert 0 < need <= (64 << 30) + 4096        # the cap include/f2nerf_hip.h documents
     need = min(need, 20 << 30)          # less than one round's worth: at least two rounds
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     overflow = torch.zeros(1, dtype=torch.int64, device=dev)

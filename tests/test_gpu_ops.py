@@ -216,20 +216,24 @@ def _ray_points(n_rays, S, seed):
     return torch.where(nrm <= 1, p, (2 - 1 / nrm) * p / nrm).contiguous()
 
 
-@pytest.mark.parametrize("L,F,log2_T,ws_frac", [(2, 8, 20, 1.0), (3, 8, 18, 0.5), (2, 2, 21, 1.0)])
-def test_hash_bwd_binned_overflow_stays_exact(capi, dev, L, F, log2_T, ws_frac):
-    """Two-level tables (more than 64 slices per level).  Skewed points (a tile's worth of them in
-    a tiny ball: eight rows carry all of their coarse levels' records) overflow the LDS queues of both
-    binning passes and the per-slice runs.  Those records go to the overflow arena of their (level,
-    bucket) and are summed exactly like the rest: the overflow counter stays 0 and two launches agree
-    BIT FOR BIT (a float-atomic fallback would make the last bits order-dependent)."""
+@pytest.mark.parametrize("L,F,log2_T,ws_frac,must_overflow", [
+    (3, 8, 20, 1.0, True), (3, 8, 18, 0.5, False), (3, 2, 21, 1.0, True)])
+def test_hash_bwd_binned_overflow_stays_exact(capi, dev, L, F, log2_T, ws_frac, must_overflow):
+    """Two-level tables (more than 64 slices per level).  Half of the points sit in a ball of radius
+    0.7: at the coarsest level they touch ~1500 distinct rows, so some slices of each bucket
+    receive many times the mean number of records and the split pass overflows its sub-slice queues
+    and per-slice runs (the skew config C5 shows at its levels 0 and 1, stronger).  Those records go
+    to the overflow arena of their (level, bucket) and are summed exactly like the rest: the overflow
+    counter stays 0 and two launches agree BIT FOR BIT (a float-atomic fallback would make the last
+    bits order-dependent)."""
     T = 1 << log2_T
     fld = util.make_field(L, F, log2_T, T * F, seed=9 + F)
     st = fld["stride"]
-    n = 90000
+    n = 200000
     pts = util.ball_points(n, seed=41)
-    pts[:1024] *= 0.004
     g = torch.Generator().manual_seed(42)
+    perm = torch.randperm(n, generator=g)
+    pts[perm[: n // 2]] *= 0.35         # scattered over all tiles: no tile piles onto one cell
     grad = torch.randn(n, L * F, generator=g) * 1e-3           # every contribution non-zero
     numel = fld["table"].numel()
     ref_tg, _ = K.hash_bwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad,
@@ -241,6 +245,11 @@ def test_hash_bwd_binned_overflow_stays_exact(capi, dev, L, F, log2_T, ws_frac):
     overflow = torch.zeros(1, dtype=torch.int64, device=dev)
     cd = capi.lib().cdll
     assert cd.f2n_hash_bwd_set_overflow_counter(overflow.data_ptr()) == 0
+    stats = torch.zeros(64, 4, dtype=torch.int32, device=dev)     # split-pass counters per level
+    import ctypes
+    cd.f2n_debug_bin_stats.argtypes = [ctypes.c_void_p]
+    cd.f2n_debug_bin_stats.restype = None
+    cd.f2n_debug_bin_stats(stats.data_ptr())
     outs = []
     try:
         for _ in range(2):
@@ -250,7 +259,10 @@ def test_hash_bwd_binned_overflow_stays_exact(capi, dev, L, F, log2_T, ws_frac):
         torch.cuda.synchronize()
     finally:
         cd.f2n_hash_bwd_set_overflow_counter(None)
-    assert int(overflow.item()) == 0
+        cd.f2n_debug_bin_stats(None)
+    if must_overflow:                          # records DID run past a queue or a run of pass B ...
+        assert int(stats[:, 2:4].sum()) > 0
+    assert int(overflow.item()) == 0           # ... and none of them became a float atomic
     assert torch.equal(outs[0], outs[1])
     scale = ref_tg.abs().max().item()
     assert (outs[0].cpu() - ref_tg).abs().max().item() <= 2e-5 * scale
