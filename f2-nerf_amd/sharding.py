@@ -33,8 +33,10 @@ def reduce_error_stats(sq_err_sum, n_values, dist=None, group=None, async_op=Fal
     async_op: return (tensor, work) without making the caller's stream wait for the collective; the
     tensor holds the global sums once work.wait() has returned (work is None without a group)."""
     dev = sq_err_sum.device if torch.is_tensor(sq_err_sum) else "cpu"
+    # (torch.full, not torch.tensor: a host scalar copied to the device is a blocking transfer that
+    # waits for everything enqueued before it -- once per step it costs a 1 ms training batch 15 %)
     stat = torch.stack([torch.as_tensor(sq_err_sum, dtype=torch.float64, device=dev).reshape(()),
-                        torch.tensor(float(n_values), dtype=torch.float64, device=dev)])
+                        torch.full((), float(n_values), dtype=torch.float64, device=dev)])
     # (also with a single rank: a one-rank group still runs the backend's collective, which is how
     # bench.py --gpus 1 exercises RCCL on a one-GPU box)
     work = None
