@@ -492,6 +492,9 @@ f2n::TrainStepResult f2n::train_step(
   // colour loss + variance loss + squared error in two launches (f2n_loss_fwd; the ATen spelling of
   // the reference, train_manager.cpp:78-96, is ~23 launches of a few microseconds each)
   Tensor var = CustomOps::WeightVar(res.weights, res.idx_start_end);
+  // (a zero weight -- the reference's schedule starts there, train_manager.cpp:85-91 -- makes the
+  // variance term's gradient exactly zero: its backward kernel is not run at all)
+  if (var_loss_weight == 0.f) var = var.detach();
   Tensor stats = f2n::train_loss(res.colors, gt_colors, var, var_loss_weight);  // {loss, c, v, sq}
   Tensor loss = stats[0];
   TrainStepResult out;
