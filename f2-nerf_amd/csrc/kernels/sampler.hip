@@ -208,6 +208,136 @@ __global__ __launch_bounds__(F2N_BLOCK) void density_march_kernel(
   if (lane == 0) kept[r] = n_kept;
 }
 
+// Four rays per wavefront, one per 16-lane DPP row, strides of 16 samples: a ray that stops after a
+// handful of samples (a trained scene seen from close by; the bench's terminating regime keeps 3.5
+// samples per ray) costs a 16-sample stride instead of a 64-sample one -- the wave scans are row
+// scans anyway, and the gathers of a stride touch as many lines either way.
+//
+// Bit-identical to density_march_kernel (and to make_stride, which f2n_sample_compact uses to
+// re-create the kept samples): the 64-lane Kogge-Stone scan adds, for the lanes of its row j,
+//   row 0: rs            row 1: rs + T0          row 2: rs + (T1 + T0)     row 3: (rs + T2) + (T1 + T0)
+// (rs = scan inside the row, Tj = total of row j) and carries carry + ((T3 + T2) + (T1 + T0)) to the
+// next 64 samples; stride j of a 64-sample block does exactly those additions here.
+struct RowScan
+{
+  float carry;    // inclusive total of the completed 64-sample blocks
+  float t0, t1p, t2;  // T0, T1 + T0, T2 of the current block
+  float last;     // inclusive value (within the block) of the previous stride's last lane
+};
+
+__device__ __forceinline__ float row_incl_scan(float v)
+{
+  v += dpp_get<0x111, 0xf, 0xf>(v, 0.f);
+  v += dpp_get<0x112, 0xf, 0xf>(v, 0.f);
+  v += dpp_get<0x114, 0xf, 0xf>(v, 0.f);
+  v += dpp_get<0x118, 0xf, 0xf>(v, 0.f);
+  return v;
+}
+// lane 15 of the own row in every lane of the row (row_newbcast:15)
+__device__ __forceinline__ float row_last(float v) { return dpp_get<0x15F, 0xf, 0xf>(v, 0.f); }
+// previous lane of the own row, `fill` in the row's first lane (row_shr:1)
+__device__ __forceinline__ float row_shift_up1(float v, float fill) { return dpp_get<0x111, 0xf, 0xf>(v, fill); }
+
+// inclusive value, within its 64-sample block, of this lane's element of stride j (0..3); updates st
+__device__ __forceinline__ float row_scan_step(float v, int j, RowScan & st, float & incl_in_block)
+{
+  const float rs = row_incl_scan(v);
+  const float tj = row_last(rs);
+  float inner;
+  if (j == 0) {
+    inner = rs;
+    st.t0 = tj;
+  } else if (j == 1) {
+    inner = rs + st.t0;
+    st.t1p = tj + st.t0;
+  } else if (j == 2) {
+    inner = rs + st.t1p;
+    st.t2 = tj;
+  } else {
+    inner = (rs + st.t2) + st.t1p;
+  }
+  incl_in_block = inner;
+  return st.carry + inner;
+}
+
+template <int F, bool POW2>
+__global__ __launch_bounds__(F2N_BLOCK) void density_march16_kernel(
+  const float * __restrict__ rays_o, const float * __restrict__ rays_d,
+  const float * __restrict__ noise, const uint16_t * __restrict__ table,
+  const int32_t * __restrict__ primes, const float * __restrict__ bias,
+  const float * __restrict__ mul, const float * __restrict__ w0, const float * __restrict__ b0,
+  int32_t * __restrict__ kept, int n_rays, int S, float step, int L, uint32_t T,
+  int64_t level_stride, float t_thresh, float density_shift)
+{
+  const int lane = lane_id(), q = lane >> 4, m = lane & 15;
+  const int r_raw = (ray_of_wave() << 2) + q;
+  const bool has_ray = r_raw < n_rays;
+  const int r = has_ray ? r_raw : n_rays - 1;  // (the spare rows of the last wave redo the last ray)
+  const RayFrame rf = load_ray(rays_o, rays_d, r);
+  const float * nrow = noise ? noise + (int64_t)r * S : nullptr;
+  const float bias0 = b0[0];
+  RowScan ns = {0.f, 0.f, 0.f, 0.f, 0.f}, ds = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float lx = 0.f, ly = 0.f, lz = 0.f;  // last sample point of the previous stride
+  int n_kept = 0;
+  bool done = !has_ray;
+  for (int k0 = 0; k0 < S; k0 += 16) {
+    const int j = (k0 >> 4) & 3;
+    const int k = k0 + m;
+    const bool valid = k < S;
+    // ---- the samples of this stride: make_stride, row by row
+    float cum, dummy;
+    if (nrow) {
+      const float nz = valid ? nrow[k] : 0.f;
+      cum = row_scan_step(nz, j, ns, dummy);
+      const float block_last = row_last(dummy);  // (T3 + T2) + (T1 + T0) once j = 3
+      if (j == 3) ns.carry = ns.carry + block_last;
+    } else {
+      cum = (float)(min(k, S - 1) + 1);
+    }
+    const float t = cum * step;
+    const float mx = rf.dx * t, my = rf.dy * t, mz = rf.dz * t;
+    const float px = rf.ox + mx, py = rf.oy + my, pz = rf.oz + mz;
+    const float qx = row_shift_up1(px, lx), qy = row_shift_up1(py, ly), qz = row_shift_up1(pz, lz);
+    const float ex = px - qx, ey = py - qy, ez = pz - qz;
+    const float dt = (k == 0) ? 0.f : sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+    lx = row_last(px);
+    ly = row_last(py);
+    lz = row_last(pz);
+    // ---- density, as in density_march_kernel
+    float x = px, y = py, z = pz;
+    contract_point(x, y, z);
+    float logit = bias0;
+    for (int l = 0; l < L; l++) {
+      const LevelParams lp = load_level(primes, bias, mul, l);
+      uint32_t row[8];
+      float w[8], acc[F];
+      corner_rows_and_weights<POW2>(x, y, z, lp, T, row, w);
+      gather_blend<F>(table + level_stride * l, row, w, acc);
+#pragma unroll
+      for (int kk = 0; kk < F; kk++) logit = fmaf(round_f16(acc[kk]), w0[l * F + kk], logit);
+    }
+    const float sigma = expf(logit - density_shift);
+    const float sec = valid ? sigma * dt : 0.f;
+    // ---- exclusive optical depth: depth_carry + wave_shift_up1(incl, 0) of the 64-lane scan
+    float incl;
+    row_scan_step(sec, j, ds, incl);
+    const float prev = row_shift_up1(incl, (j == 0) ? 0.f : ds.last);
+    const float depth = ds.carry + prev;
+    ds.last = row_last(incl);
+    if (j == 3) ds.carry = ds.carry + ds.last;
+    const float trans = expf(-depth);
+    const bool keep = valid && !done && (trans > t_thresh);
+    const unsigned long long mk = __ballot(keep);
+    const int cnt = __popc((uint32_t)(mk >> (16 * q)) & 0xffffu);
+    if (!done) {
+      n_kept += cnt;
+      if (cnt < min(16, S - k0)) done = true;  // the mask is a prefix: nothing later survives
+    }
+    if (__ballot(!done) == 0ull) break;
+  }
+  if (has_ray && m == 0) kept[r_raw] = n_kept;
+}
+
 // ---- f2n_density_scan ---------------------------------------------------------------------------
 // The keep-prefix of every ray from an ALREADY COMPUTED encoding of all its samples (channel-major
 // [C, n_all]): same logit FMA chain, same scan and same threshold test as density_march_kernel, so
@@ -394,13 +524,21 @@ extern "C" int f2n_density_march(
   if (!rays_o || !rays_d || !table_f16 || !primes || !bias || !mul || !w0 || !b0 || !kept)
     return F2N_E_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(table_f16) % (2u * F)) return F2N_E_INVALID_ARG;
-  const dim3 grid(f2n_div_up(n_rays, F2N_WAVES_PER_BLOCK)), block(F2N_BLOCK);
+  // four rays per wavefront (16-sample strides) unless F2N_OPT_MARCH = 1 asks for one (64)
+  const bool rows = f2n_get_option(F2N_OPT_MARCH) == 0;
+  const dim3 grid(f2n_div_up(n_rays, F2N_WAVES_PER_BLOCK * (rows ? 4 : 1))), block(F2N_BLOCK);
   hipStream_t s = (hipStream_t)stream;
   const bool p2 = is_pow2(T);
 #define F2N_MARCH(FF, P2)                                                                         \
-  hipLaunchKernelGGL(                                                                             \
-    (density_march_kernel<FF, P2>), grid, block, 0, s, rays_o, rays_d, noise, table_f16, primes,  \
-    bias, mul, w0, b0, kept, n_rays, S, step, L, T, level_stride, t_thresh, density_shift)
+  if (rows)                                                                                       \
+    hipLaunchKernelGGL(                                                                           \
+      (density_march16_kernel<FF, P2>), grid, block, 0, s, rays_o, rays_d, noise, table_f16,      \
+      primes, bias, mul, w0, b0, kept, n_rays, S, step, L, T, level_stride, t_thresh,             \
+      density_shift);                                                                             \
+  else                                                                                            \
+    hipLaunchKernelGGL(                                                                           \
+      (density_march_kernel<FF, P2>), grid, block, 0, s, rays_o, rays_d, noise, table_f16, primes,\
+      bias, mul, w0, b0, kept, n_rays, S, step, L, T, level_stride, t_thresh, density_shift)
   switch (F) {
     case 1: if (p2) F2N_MARCH(1, true); else F2N_MARCH(1, false); break;
     case 2: if (p2) F2N_MARCH(2, true); else F2N_MARCH(2, false); break;

@@ -62,6 +62,14 @@ def test_density_march_and_compact(capi, dev, L, F, log2_T, S, step, bias0, trai
               field.bias_pool.detach().to(dev), field.mul.to(dev), w0, b0, kept, n_rays, S, step,
               L, F, field.T, field.level_stride, 1e-4, 3.0)
     got = kept.cpu()
+    # the one-ray-per-wavefront march (strides of 64) and the default four-rays-per-wavefront one
+    # (strides of 16) perform the same additions in the same order: identical counts, always
+    kept64 = torch.zeros(n_rays, dtype=torch.int32, device=dev)
+    with capi.option("MARCH", 1):
+        capi.call("density_march", d_o, d_d, d_noise, table16, field.prim_pool.to(dev),
+                  field.bias_pool.detach().to(dev), field.mul.to(dev), w0, b0, kept64, n_rays, S, step,
+                  L, F, field.T, field.level_stride, 1e-4, 3.0)
+    assert torch.equal(kept64.cpu(), got)
     # T is compared against a threshold: a ray whose T sits within rounding of 1e-4 may keep one
     # sample more or less.  Everything else must agree exactly.
     diff = (got - num).abs()
