@@ -417,6 +417,17 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       gk[k] = round_f16(g_cur[k] * a.grad_scale);
       any |= (gk[k] != 0.f);
     }
+    // The prefetched gradient is taken over BEFORE this level's flush issues its stores.  vmcnt counts
+    // loads and stores alike, in order: left at the top of the next level, the wait for these
+    // loads was a wait for every store of the flush as well.
+    auto take_prefetch = [&]() {
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): only the prefetch (and older stores) are out
+#pragma unroll
+      for (int k = 0; k < F; k++) {
+        g_cur[k] = g_nxt[k];
+        asm volatile("" : "+v"(g_cur[k]));  // (the copy happens here, not after the stores)
+      }
+    };
     const bool active = valid && any;  // the reference skips all-zero channel groups (:133)
     uint32_t row[8];
     float w[8];
@@ -459,58 +470,46 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
     // wave w copies the queues of buckets w, w+16, ... to their workspace regions and records the
     // counts ([level][bucket][tile] so that pass B / C read them coalesced)
     auto flush = [&](int cap, int64_t tile_g, bool watch_overflow) {
+      // (the thread id is laundered: everything derived from it below is loop-invariant, and the
+      // compiler would otherwise compute it all before the level loop and keep -- spill -- it)
+      uint32_t tid_f = (uint32_t)threadIdx.x;
+      asm volatile("" : "+v"(tid_f));
+      const int lane = (int)(tid_f & 63u), wave = (int)(tid_f >> 6);
       uint32_t * region0 =
         ws_records + ((size_t)l * n_tiles_g + tile_g) * a.n_buckets * (size_t)a.qcap * KW;
       if constexpr (!Rec<F>::kSoA) {
         if (a.n_buckets == 4 * kWaves) {
-          // 64 buckets, four per wave (w, w+16, w+32, w+48): their queues are copied as ONE flat list
-          // -- lane f takes the f-th record of the four queues together -- so that the sparse queues
-          // of a tile whose contributions mostly underflow (a dozen records each) cost one 64-lane
-          // pass and ~50 instructions instead of four masked passes and ~180.  This kernel is bound
-          // by instruction issue and the flush was its largest piece (bench workload: the whole
-          // backward 2.27 -> 2.11 ms; full queues, 512 records per wave, lose 2-5 %).
-          uint32_t c[4];
-          bool over = false;  // (scalar: the counts are wave-uniform)
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const uint32_t asked = (uint32_t)__builtin_amdgcn_readfirstlane((int)qcount[wave + kWaves * u]);
-            over |= asked > (uint32_t)cap;
-            c[u] = min(asked, (uint32_t)cap);
-          }
+          // 64 buckets, four per wave (w, w+16, w+32, w+48), one per 16-lane group: lane (u, i)
+          // copies records i, i+16, ... of queue u.  The first two records and the count are read
+          // together, speculatively -- with sparse gradients (a dozen records per queue) that is the
+          // whole flush: one LDS round trip, then the stores.  All sixteen waves of the tile do this
+          // at the same moment with nothing else to run, so the length of the dependent chain is what
+          // the flush costs, not its idle lanes: walking the four queues as one flat list (counts to
+          // scalars, a prefix, a search per lane: round 2) kept every lane busy and was slower (bin
+          // pass of the bench workload 2.02 -> 1.89 ms together with the register fixes below).
+          const uint32_t u = (uint32_t)lane >> 4, i0 = (uint32_t)lane & 15u;
+          const uint32_t b = (uint32_t)wave + (uint32_t)kWaves * u;
+          const uint2 * src = reinterpret_cast<const uint2 *>(queue) + __umul24(b, (uint32_t)cap);
+          uint2 * dst = reinterpret_cast<uint2 *>(region0) + __umul24(b, (uint32_t)a.qcap);
+          const uint32_t asked = qcount[b];
+          const uint2 r0 = src[i0], r1 = src[min(i0 + 16u, (uint32_t)cap - 1u)];  // (inside the queue)
+          const uint32_t c = min(asked, (uint32_t)cap);
           // a queue overflowed (its records left as global atomics): this tile's contributions pile
           // onto few rows here (e.g. the samples of rays that stop right in front of one camera: a
           // dozen rows per tile and level, 80 us of same-address atomics) -- combine from the next
           // level on
-          if (watch_overflow && over && lane == 0) comb_state[0] = 1u;
-          const uint32_t p1 = c[0], p2 = p1 + c[1], p3 = p2 + c[2], total = p3 + c[3];
-          const uint2 * src = reinterpret_cast<const uint2 *>(queue) + (uint32_t)wave * (uint32_t)cap;
-          uint2 * dst = reinterpret_cast<uint2 *>(region0) + (uint32_t)wave * (uint32_t)a.qcap;
-          const uint32_t su = (uint32_t)(kWaves * cap), du = (uint32_t)(kWaves * a.qcap);
-          auto locate = [&](uint32_t f, uint32_t & from, uint32_t & to) {
-            const bool g1 = f >= p1, g2 = f >= p2, g3 = f >= p3;
-            const uint32_t u = (g1 ? 1u : 0u) + (g2 ? 1u : 0u) + (g3 ? 1u : 0u);
-            const uint32_t i = f - (g1 ? c[0] : 0u) - (g2 ? c[1] : 0u) - (g3 ? c[2] : 0u);
-            from = __umul24(u, su) + i;
-            to = __umul24(u, du) + i;
-          };
-          uint32_t f = (uint32_t)lane;
-          for (; f + 64u < total; f += 128u) {  // two passes at a time: both loads before the stores
-            uint32_t from0, to0, from1, to1;
-            locate(f, from0, to0);
-            locate(f + 64u, from1, to1);
-            const uint2 v0 = src[from0], v1 = src[from1];
-            dst[to0] = v0;
-            dst[to1] = v1;
+          if (watch_overflow && __ballot(asked > (uint32_t)cap) != 0ull && lane == 0) comb_state[0] = 1u;
+          if (i0 < c) dst[i0] = r0;
+          if (i0 + 16u < c) dst[i0 + 16u] = r1;
+          for (uint32_t i = i0 + 32u; __ballot(i < c) != 0ull; i += 32u) {
+            const bool p0 = i < c, p1 = i + 16u < c;
+            uint2 v0 = make_uint2(0u, 0u), v1 = make_uint2(0u, 0u);
+            if (p0) v0 = src[i];
+            if (p1) v1 = src[i + 16u];
+            if (p0) dst[i] = v0;
+            if (p1) dst[i + 16u] = v1;
           }
-          if (f < total) {
-            uint32_t from0, to0;
-            locate(f, from0, to0);
-            dst[to0] = src[from0];
-          }
-          if (lane < 4) {
-            const uint32_t mine = lane == 0 ? c[0] : lane == 1 ? c[1] : lane == 2 ? c[2] : c[3];
-            ws_counts[((size_t)l * a.n_buckets + (wave + kWaves * lane)) * n_tiles_g + tile_g] = mine;
-          }
+          if (i0 == 0u) ws_counts[((size_t)l * a.n_buckets + b) * n_tiles_g + tile_g] = c;
           return;
         }
         // the LDS reads of up to four buckets are issued before the first store
@@ -563,10 +562,12 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       // ---- combine: equal rows of this tile are summed in LDS before they become records --------
       {  // zero the sums (32 KiB); tags need no reset: a slot is only read after a write of this level
         uint4 * zp = reinterpret_cast<uint4 *>(comb_acc);
-        zp[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
-        zp[threadIdx.x + kBinBlock] = make_uint4(0u, 0u, 0u, 0u);
-        if (threadIdx.x < kCombAccWords / 4 - 2 * kBinBlock)
-          zp[threadIdx.x + 2 * kBinBlock] = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t zero = 0u;  // (laundered: four registers of zeros were being kept across the level loop)
+        asm volatile("" : "+v"(zero));
+        const uint4 z4 = make_uint4(zero, zero, zero, zero);
+        zp[threadIdx.x] = z4;
+        zp[threadIdx.x + kBinBlock] = z4;
+        if (threadIdx.x < kCombAccWords / 4 - 2 * kBinBlock) zp[threadIdx.x + 2 * kBinBlock] = z4;
       }
       if (active) {
         const LevelParams lp = load_level(primes, bias, mul, l);
@@ -639,6 +640,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
         }
       }
       __syncthreads();
+      take_prefetch();
       flush(a.qcap_comb, tile, false);
       // Combine the next level too?  Yes while the sampling is still dense relative to its cells, or
       // while the records saved (measured here, scaled by the ~1.6x more distinct rows a finer level
@@ -754,11 +756,10 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
           }
           __syncthreads();
         }
+        if (g == 0) take_prefetch();
         flush(a.qcap, tile * a.groups + g, comb_allowed);
       }
     }
-#pragma unroll
-    for (int k = 0; k < F; k++) g_cur[k] = g_nxt[k];
   }
 }
 

@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--levels", type=int, default=0, help="override L")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="kernel route (f2n_set_option) for the 'current' library, e.g. BIN_SPLIT=1")
+    ap.add_argument("--only", default="", help="time just this library (a --other name, or 'current')")
     ap.add_argument("--other", action="append", default=[], metavar="NAME",
                     help="also time tools/ab/libf2nerf_hip_NAME.so (an experimental build)")
     args = ap.parse_args()
@@ -109,6 +110,8 @@ def main():
         libs.append(("round 1", old))
     for name in args.other:
         libs.append((name, ctypes.CDLL(os.path.join(ROOT, "tools", "ab", "libf2nerf_hip_%s.so" % name))))
+    if args.only:
+        libs = [(nm, lb) for nm, lb in libs if nm == args.only]
     print("config %s: n=%d (%d rays x %d) L=%d F=%d T=2^%d, points=%s" % (args.config, n, n_rays, S, L, F, log2_T, args.points))
     stream = torch.cuda.current_stream().cuda_stream
     for name, lib in libs:
@@ -120,7 +123,7 @@ def main():
             continue
         if args.ws_gib > 0 and name == "current":
             need = int(args.ws_gib * 2 ** 30) // 256 * 256
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = torch.zeros(need, dtype=torch.uint8, device=dev)
         fn = lib.f2n_hash_bwd_binned
         fn.restype = ctypes.c_int
         fn.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
