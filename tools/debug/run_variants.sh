@@ -5,7 +5,7 @@ cd /tmp; export TMPDIR=/tmp
 for v in "$@"; do
   out=$GRAFT_REPO_ROOT/gpurun_out/r3/var_$v
   mkdir -p $out
-  ( cd $GRAFT_REPO_ROOT/tools && timeout -k 10 150 rocprofv3 --kernel-trace --stats -d $out -o p --output-format csv -- python3 ab_hash_bwd.py --config c2 --points train --grad-scale $gs --other $v --only $v --reps 10 > $out/log.txt 2>&1 ) || exit 1
+  ( cd $GRAFT_REPO_ROOT/tools && timeout -k 10 150 rocprofv3 --kernel-trace --stats -d $out -o p --output-format csv -- python3 ab_hash_bwd.py --config ${CFG:-c2} --points ${PTS:-train} --grad-scale $gs --other $v --only $v --reps ${REPS:-10} > $out/log.txt 2>&1 ) || exit 1
   python3 - $out $v <<'P'
 import csv,sys,glob
 f=glob.glob(sys.argv[1]+'/**/*kernel_stats.csv',recursive=True)[0]
