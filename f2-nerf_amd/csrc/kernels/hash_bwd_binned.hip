@@ -58,6 +58,8 @@ constexpr int kCombineRepeats = 448;       // ... or lanes (of the 768 that have
                                            // their DPP row) with a gradient above the f16 underflow whose
                                            // level-0 cell is that of one of those four: samples piled
                                            // onto few cells without forming runs
+constexpr int kCombinePiledPerCell = 64;   // ... or non-zero level-0 contributions (estimated from the gradient's
+                                           // magnitude) per distinct level-0 cell of the tile: a pile
 constexpr int kSplitBlock = 512;       // pass B: four workgroups per CU (it is latency-bound)
 constexpr int kSplitQueueWords = 9216;   // 36 KiB: four workgroups per CU
 constexpr int kSplitRegions = 2;       // regions a wave of pass B ingests per round
@@ -298,14 +300,17 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
   constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
   constexpr uint32_t kSlots = 4096 / F;  // combine table: slots (tags), F 64-bit sums each
   // channel-major with an odd pitch, for the same bank reason as SliceAcc (F >= 2: 4096 + F words)
+  // slot of a row in the combine table: a multiplicative hash, not the row's low bits (EXPERIMENT)
+  auto comb_slot = [](uint32_t r) { return (r ^ (r >> __builtin_ctz(kSlots))) & (kSlots - 1u); };
   auto comb_index = [](uint32_t slot, int k) { return (uint32_t)k * (kSlots + (F > 1 ? 1u : 0u)) + slot; };
   __shared__ __attribute__((aligned(16))) uint32_t queue[kBinQueueWords];
   __shared__ uint32_t qcount[kMaxBuckets];
   __shared__ unsigned long long sat_acc[8 * F];  // cell (0,0,0): exact sums per corner and channel
   // [0] combine the coming level, [1] non-zero contributions of this level, [2] lanes of the tile
   // whose level-0 cell equals the previous sample's, [3] lanes that have a previous sample,
-  // [4] mean run length at level 0 (x256), [5] records that overflowed this level
-  __shared__ uint32_t comb_state[6];
+  // [4] mean run length at level 0 (x256), [5] records that overflowed this level, [6] estimate of
+  // the tile's non-zero level-0 contributions
+  __shared__ uint32_t comb_state[7];
   unsigned long long * const comb_acc =
     reinterpret_cast<unsigned long long *>(queue + kBinQueueWords - kCombAccWords);
   uint32_t * const comb_tag = queue + kBinQueueWords - kCombAccWords - kCombTagWords;
@@ -329,7 +334,8 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
   for (int k = 0; k < F; k++) g_cur[k] = grad_out[pc * a.g_ld_point + (int64_t)k * a.g_ld_chan];
 
   const bool comb_allowed = a.combine && a.groups == 1;
-  if (threadIdx.x < 6) comb_state[threadIdx.x] = 0u;
+  if (threadIdx.x < 7) comb_state[threadIdx.x] = 0u;
+  if (threadIdx.x < 32) queue[threadIdx.x] = 0u;  // prologue: bit set of the tile's level-0 cells
   __syncthreads();
   if (comb_allowed) {
     // how many consecutive samples share a level-0 cell?  (points are ray-major: the lanes of a wave
@@ -361,12 +367,35 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
 #pragma unroll
     for (int k = 0; k < F; k++) big = fmaxf(big, fabsf(g_cur[k] * a.grad_scale));
     const unsigned long long m_repeat = __ballot(repeat && big >= 1.52587890625e-05f);
+    // ... or is the whole tile a pile on a handful of cells, small gradients or not?  (Rays that
+    // stop in front of one camera, gradients below the magnitude asked for above: level 0 was taken
+    // plain, its queues overflowed into same-address global atomics, and only that overflow switched
+    // the combine on, from level 1 -- half the backward's time in the bench's terminating regime.)
+    // Contributions that survive the f16 underflow, estimated per lane from its gradient (a product
+    // g w_d survives when w_d >= 2^-25 / g: all eight corners, about four, about one, none), against
+    // the tile's distinct level-0 cells (a bit per cell of a 16 x 8 x 8 block; a long thin tile
+    // aliases and looks smaller than it is: the price is one combined level, after which the
+    // numbers measured on that level decide).
+    const float big_s = big * 33554432.f;  // x 2^25
+    const unsigned long long m8 = __ballot(valid && big_s >= 64.f), m4 = __ballot(valid && big_s >= 8.f),
+                             m1 = __ballot(valid && big_s >= 2.f);
+    const uint32_t nnz_est = 4u * (uint32_t)__popcll(m8) + 3u * (uint32_t)__popcll(m4) + (uint32_t)__popcll(m1);
+    if (valid) {
+      const uint32_t h = (uint32_t)(cx & 15) | ((uint32_t)(cy & 7) << 4) | ((uint32_t)(cz & 7) << 7);
+      atomicOr(&queue[h >> 5], 1u << (h & 31u));
+    }
     if (lane == 0) {
       atomicAdd(&comb_state[2], (uint32_t)__popcll(m_same));
       atomicAdd(&comb_state[3], (uint32_t)__popcll(m_prev));
       atomicAdd(&comb_state[5], (uint32_t)__popcll(m_repeat));
+      atomicAdd(&comb_state[6], nnz_est);
     }
     __syncthreads();
+    uint32_t n_cells = 0u;
+    if (wave == 0) {
+      n_cells = lane < 32 ? (uint32_t)__popc(queue[lane]) : 0u;
+      n_cells = (uint32_t)__builtin_amdgcn_readlane(wave_incl_scan_i32((int)n_cells), 63);
+    }
     if (threadIdx.x == 0) {
       const uint32_t breaks = comb_state[3] - comb_state[2] + (uint32_t)kWaves;  // runs in the tile
       // mean run (x256) = 256 (lanes + waves) / breaks; the comparison needs no division, and the
@@ -374,7 +403,9 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
       // instructions of this one thread while 1023 wait)
       const uint64_t lanes_q8 = (uint64_t)(comb_state[3] + kWaves) << 8;
       // (at most 768 of 1024 lanes can repeat; 640 = five in six of those with a look-back)
-      const bool on = lanes_q8 >= (uint64_t)kCombineMinRunQ8 * breaks || comb_state[5] >= (uint32_t)kCombineRepeats;
+      const bool on = lanes_q8 >= (uint64_t)kCombineMinRunQ8 * breaks ||
+                      comb_state[5] >= (uint32_t)kCombineRepeats ||
+                      comb_state[6] >= (uint32_t)kCombinePiledPerCell * n_cells;
       comb_state[0] = on ? 1u : 0u;
       if (on) comb_state[4] = (uint32_t)(lanes_q8 / breaks);
       if (a.stats) {
@@ -573,7 +604,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
         const LevelParams lp = load_level(primes, bias, mul, l);
         corner_rows_and_weights<POW2>(x, y, z, lp, a.T, row, w);
 #pragma unroll
-        for (int d = 0; d < 8; d++) comb_tag[row[d] & (kSlots - 1u)] = row[d];  // some writer wins
+        for (int d = 0; d < 8; d++) comb_tag[comb_slot(row[d])] = row[d];  // some writer wins
       }
       __syncthreads();
       uint32_t n_nz = 0u;
@@ -584,7 +615,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
           corner_value(d, val);
           if (val_all_zero<F>(val)) continue;
           n_nz++;
-          const uint32_t slot = row[d] & (kSlots - 1u);
+          const uint32_t slot = comb_slot(row[d]);
           bool finite = true;
 #pragma unroll
           for (int k = 0; k < F; k++) finite &= !f16_bits_nonfinite(val_channel_bits<F>(val, k));
@@ -597,6 +628,7 @@ __global__ __launch_bounds__(kBinBlock) void hash_bwd_bin_kernel(
             }
           } else {
             enqueue(row[d], val, a.qcap_comb);  // lost the slot to another row: an ordinary record
+            if (a.stats) atomicAdd(a.stats + 4 * (32 + l), 1u);
           }
         }
       }

@@ -309,12 +309,18 @@ def test_hash_bwd_binned_combine(capi, dev, L, F, log2_T, S):
     assert (out[0] - out[1]).abs().max().item() <= 1e-6 * scale
 
 
-def test_hash_bwd_binned_hot_spot(capi, dev):
+@pytest.mark.parametrize("grad_std", [1e-2, 2e-6])
+def test_hash_bwd_binned_hot_spot(capi, dev, grad_std):
     """Rays that stop right in front of one camera: three or four samples each, all in the same few
     cells, every gradient non-zero -- a tile's 8192 contributions land on a dozen rows per level.
     Plain binning overflows its queues there (the records leave as same-address atomics); the tile
     must notice (repeating cells / an overflowing queue), combine from then on, and stay exact: sums
-    in the combined levels are bit-equal to the oracle's exact sums up to its own f32 rounding."""
+    in the combined levels are bit-equal to the oracle's exact sums up to its own f32 rounding.
+    Small gradients (2e-6: below the magnitude the repeating-cells test asks for, above the f16
+    underflow) must be noticed BEFORE level 0 as well -- surviving contributions per distinct
+    level-0 cell -- so that (next to) no record of the coarse levels ends as a float atomic: at most
+    a few dozen of 4.5 million at L = 8, against a quarter of a million at level 0 alone before
+    (round 3)."""
     L, F, log2_T = 16, 2, 19
     T = 1 << log2_T
     fld = util.make_field(L, F, log2_T, None, seed=5)
@@ -329,7 +335,7 @@ def test_hash_bwd_binned_hot_spot(capi, dev):
     pts = (o + d * t).reshape(-1, 3)[keep].contiguous()
     n = pts.shape[0]
     assert n >= 65536
-    grad = torch.randn(n, L * F, generator=g) * 1e-2
+    grad = torch.randn(n, L * F, generator=g) * grad_std
     numel = fld["table"].numel()
     ref_tg, _ = K.hash_bwd(pts, fld["table16"], fld["primes"], fld["bias"], fld["mul"], grad,
                            numel, L, F, T, fld["stride"], 128.0, parallel=True)
@@ -337,10 +343,26 @@ def test_hash_bwd_binned_hot_spot(capi, dev):
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     dd = _to(dev, pts, fld["primes"], fld["bias"], fld["mul"], grad.t().contiguous())
     scale = ref_tg.abs().max().item()
+    cd = capi.lib().cdll
     for combine_off in (0, 1):
-        with capi.option("BWD_COMBINE", combine_off):
-            tg = torch.zeros(numel, device=dev)
-            capi.call("hash_bwd_binned", *dd, 1, n, tg, n, L, F, T, fld["stride"], 128.0, ws, need)
+        overflow = torch.zeros(1, dtype=torch.int64, device=dev)
+        assert cd.f2n_hash_bwd_set_overflow_counter(overflow.data_ptr()) == 0
+        try:
+            with capi.option("BWD_COMBINE", combine_off):
+                tg = torch.zeros(numel, device=dev)
+                capi.call("hash_bwd_binned", *dd, 1, n, tg, n, L, F, T, fld["stride"], 128.0, ws, need)
+                after_all = int(overflow.item())
+                overflow.zero_()
+                # the coarse half of the levels alone: every tile must combine all of them
+                tg8 = torch.zeros(numel, device=dev)
+                capi.call("hash_bwd_binned", *dd, 1, n, tg8, n, 8, F, T, fld["stride"], 128.0, ws, need)
+                coarse_only = int(overflow.item())
+        finally:
+            cd.f2n_hash_bwd_set_overflow_counter(None)
+        if combine_off == 0:
+            assert coarse_only <= 100 and after_all <= 200, (coarse_only, after_all)
+        else:
+            assert coarse_only > 100000     # (what the combine is there for)
         # (with the combine off, or before a tile has noticed, overflowing records are float atomics:
         # order-dependent in the last bits of sums of thousands of terms)
         assert (tg.cpu() - ref_tg).abs().max().item() <= 1e-4 * scale, combine_off

@@ -30,4 +30,6 @@ def report(cdll, stats, L, out=sys.stdout):
                   file=out)
         if int(st[l, 0]):
             print("    level %2d: %6d tiles combined, %5.0f non-zero contributions -> %5.0f records per tile"
-                  % (l, int(st[l, 0]), int(st[l, 1]) / int(st[l, 0]), int(st[l, 2]) / int(st[l, 0])), file=out)
+                  % (l, int(st[l, 0]), int(st[l, 1]) / int(st[l, 0]), int(st[l, 2]) / int(st[l, 0]))
+                  + ("  (%.0f of them contributions that lost their slot of the table)" % (int(st[32 + l, 0]) / int(st[l, 0]))
+                     if int(st[32 + l, 0]) else ""), file=out)
