@@ -81,6 +81,9 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline: skip the separately timed extra legs of the default line "
                          "(8x8 pixel tiles, non-zero-gradient table backward, config C5)")
+    ap.add_argument("--no-grad-in-place", action="store_true",
+                    help="A/B: hand every chunk's table gradient to autograd (a 64 MiB fill and add per "
+                         "chunk) instead of adding into feat_pool.grad directly")
     ap.add_argument("--no-collective-at-1", action="store_true",
                     help="at --gpus 1 do not create the one-rank RCCL group (the path's all-reduce then "
                          "is skipped, as in rounds 1-2)")
@@ -825,6 +828,8 @@ def main():
     ren = H.Renderer(args.n_images, n_levels=L, n_channels=F, log2_table=args.log2_table,
                      max_samples=S, step=step_len)
     params = ren.named_parameters()
+    if args.no_grad_in_place:
+        ren.scene_field.set_accumulate_in_place(False)
     with torch.no_grad():
         # "trained-like" table: N(0, 0.1^2) exercises the f16 range and real gradients
         params["scene_field.feat_pool"].normal_(0.0, 0.1)

@@ -135,6 +135,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
         return torch::autograd::Hash3DAnchoredFunction::apply(x, s.feat_pool_, torch::IValue(info))[0];
       },
       "Hash3DAnchoredFunction::apply(points, feat_pool, info)[0] on already-contracted points")
+    .def(
+      "set_accumulate_in_place", [](Hash3DAnchored & s, bool on) { s.options_.accumulate_in_place = on; },
+      "Hash3DAnchoredOptions::accumulate_in_place: add into feat_pool.grad directly once it exists")
     .def_readonly("pool_size", &Hash3DAnchored::pool_size_)
     .def_readonly("local_size", &Hash3DAnchored::local_size_)
     .def_readonly("level_stride", &Hash3DAnchored::level_stride_)

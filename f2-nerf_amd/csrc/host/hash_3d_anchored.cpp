@@ -294,7 +294,18 @@ variable_list Hash3DAnchoredFunction::backward(AutogradContext * ctx, variable_l
   // points need a gradient only for pose optimisation; training rays are data
   const bool want_points = ctx->needs_input_grad(0);
   Tensor points_grad = want_points ? torch::empty({n, 3}, points.options()) : Tensor();
-  Tensor embeds_grad = torch::zeros_like(feat_pool);
+  // add into the gradient feat_pool already has (options_.accumulate_in_place), or start a new one
+  Tensor embeds_grad;
+  bool in_place = false;
+  if (field->options_.accumulate_in_place && !torch::GradMode::is_enabled() && feat_pool.is_leaf()) {
+    const Tensor & have = feat_pool.grad();
+    if (have.defined() && have.is_contiguous() && have.scalar_type() == torch::kFloat32 &&
+        have.device() == feat_pool.device() && have.sizes() == feat_pool.sizes()) {
+      embeds_grad = have;
+      in_place = true;
+    }
+  }
+  if (!in_place) embeds_grad = torch::zeros_like(feat_pool);
   void * stream = f2n::current_stream(points);
   // Large training batches: bin the contributions by table slice into a scratch workspace and
   // reduce them in LDS (no scattered atomics; exact, order-independent sums).  The recommended
@@ -345,7 +356,7 @@ variable_list Hash3DAnchoredFunction::backward(AutogradContext * ctx, variable_l
         F, (uint32_t)field->local_size_, field->level_stride_, grad_scale, stream),
       "f2n_hash_bwd");
   }
-  return {points_grad, embeds_grad, Tensor()};
+  return {points_grad, in_place ? Tensor() : embeds_grad, Tensor()};
 }
 
 }  // namespace torch::autograd

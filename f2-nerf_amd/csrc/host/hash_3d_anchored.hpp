@@ -26,6 +26,12 @@ struct Hash3DAnchoredOptions
                              // level, so adjacent levels overlap)
   int64_t mlp_out_dim = 16;
   bool binned_backward = true;  // large batches: f2n_hash_bwd_binned (needs a scratch workspace)
+  // The table's gradient is 64 MiB.  Handed to autograd per backward call it costs a zero fill and,
+  // from the second call of an iteration on (a view rendered in chunks), an accumulation pass over
+  // all of it -- 48 us per call for a kernel that may take 180.  When feat_pool already has a
+  // gradient, the kernels add into it directly and autograd is told "no gradient" for that input.
+  // Tensor hooks on feat_pool do not see those calls; switch it off if you rely on them.
+  bool accumulate_in_place = true;
   torch::Device device = f2n::default_device();
 };
 

@@ -351,6 +351,36 @@ def test_pose_gradient_path(host, dev):
     _close(d_g.grad.cpu(), d_r.grad, 5e-2, 2e-3)
 
 
+@pytest.mark.parametrize("n", [4096, 131072])
+def test_table_gradient_accumulates_in_place(host, dev, n):
+    """Hash3DAnchoredOptions::accumulate_in_place: from the second backward call of an iteration on
+    the kernels add into feat_pool.grad directly (autograd gets "no gradient" for that input); the
+    sum over three calls must be what autograd's own accumulation gives -- small batch (atomic
+    kernel) and binned backward -- and the gradient tensor must stay the same storage."""
+    host.manual_seed(3)
+    f = host.Hash3DAnchored(6, 2, 14, 0, "cuda:0")
+    g = torch.Generator().manual_seed(5)
+    xs = [((torch.rand(n, 3, generator=g) * 3.0 - 1.5)).to(dev) for _ in range(3)]
+    ws = [torch.randn(n, 12, generator=g).to(dev) * 1e-2 for _ in range(3)]
+    sums = {}
+    for in_place in (False, True):
+        f.set_accumulate_in_place(in_place)
+        f.feat_pool.grad = None
+        ptrs = []
+        for x, w in zip(xs, ws):
+            (f.encode(x) * w).sum().backward()
+            ptrs.append(f.feat_pool.grad.data_ptr())
+        sums[in_place] = f.feat_pool.grad.clone()
+        if in_place:
+            assert ptrs[0] == ptrs[1] == ptrs[2]
+    f.set_accumulate_in_place(True)
+    ref = sums[False]
+    assert ref.abs().max().item() > 0
+    # the same exact slice sums, added to the running value in a different order of f32 additions
+    assert (sums[True] - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    assert ((sums[True] - ref).norm() / ref.norm()).item() < 1e-6
+
+
 def test_shadow_table_tracks_optimizer(host, dev):
     """The persistent f16 table must equal an RNE cast of the current f32 master after every
     in-place update (reference re-casts on each call, hash_3d_anchored.cu:169)."""
