@@ -338,6 +338,155 @@ __global__ __launch_bounds__(F2N_BLOCK) void density_march16_kernel(
   if (has_ray && m == 0) kept[r_raw] = n_kept;
 }
 
+// ---- eight rays per wavefront --------------------------------------------------------------------
+// A ray that stops after three or four samples still pays for the 16 of its first stride above.
+// Here a ray owns HALF a DPP row (8 lanes) and strides are 8 samples: half the evaluations where
+// rays stop early.  The 64-lane scan's additions are reproduced as before, now half a row at a
+// time: the first half of a row is the row scan's steps 1, 2, 4 (step 8 adds nothing below lane 8);
+// the second half needs, for its first lanes, what the first half's lanes 7 / 6,7 / 4..7 held after
+// steps 0 / 1 / 2 (kept in registers, fetched with row_shl) and adds the first half's own result at
+// step 8.  Same counts, bit for bit (tests/test_gpu_fused.py).
+struct HalfScan
+{
+  float carry, t0, t1p, t2, last;  // as RowScan
+  float pv, pa, pb, pc;            // the first half's values after steps 0, 1, 2, 4 (per lane)
+};
+
+// lane 7 of the own 8-lane group in every lane of the group
+__device__ __forceinline__ float group_last(float v, int lane)
+{
+  const float lo = dpp_get<0x157, 0xf, 0xf>(v, 0.f), hi = dpp_get<0x15F, 0xf, 0xf>(v, 0.f);
+  return (lane & 8) ? hi : lo;
+}
+
+// value after the row scan (16 lanes of the 64-lane scan) of the element this lane holds: m = lane
+// within the group = lane within the half row, h = which half of the row this stride is
+__device__ __forceinline__ float half_row_scan(float v, int m, int h, HalfScan & st)
+{
+  // (every DPP move is executed by ALL lanes and selected afterwards: inside a conditional
+  // expression it would run with the other lanes switched off, and a lane that reads a switched-off
+  // lane gets the fill value)
+  float a, b, c;
+  if (h == 0) {  // (wave-uniform)
+    const float s1 = dpp_get<0x111, 0xf, 0xf>(v, 0.f);
+    a = v + (m >= 1 ? s1 : 0.f);
+    const float s2 = dpp_get<0x112, 0xf, 0xf>(a, 0.f);
+    b = a + (m >= 2 ? s2 : 0.f);
+    const float s4 = dpp_get<0x114, 0xf, 0xf>(b, 0.f);
+    c = b + (m >= 4 ? s4 : 0.f);
+    st.pv = v;
+    st.pa = a;
+    st.pb = b;
+    st.pc = c;
+    return c;
+  }
+  const float s1 = dpp_get<0x111, 0xf, 0xf>(v, 0.f), f1 = dpp_get<0x107, 0xf, 0xf>(st.pv, 0.f);
+  a = v + (m >= 1 ? s1 : f1);
+  const float s2 = dpp_get<0x112, 0xf, 0xf>(a, 0.f), f2 = dpp_get<0x106, 0xf, 0xf>(st.pa, 0.f);
+  b = a + (m >= 2 ? s2 : f2);
+  const float s4 = dpp_get<0x114, 0xf, 0xf>(b, 0.f), f4 = dpp_get<0x104, 0xf, 0xf>(st.pb, 0.f);
+  c = b + (m >= 4 ? s4 : f4);
+  return c + st.pc;
+}
+
+// as row_scan_step, for half j * 2 + h of the 64-sample block
+__device__ __forceinline__ float half_scan_step(
+  float v, int j, int h, int m, int lane, HalfScan & st, float & incl_in_block)
+{
+  const float rs = half_row_scan(v, m, h, st);
+  float inner;
+  if (j == 0) inner = rs;
+  else if (j == 1) inner = rs + st.t0;
+  else if (j == 2) inner = rs + st.t1p;
+  else inner = (rs + st.t2) + st.t1p;
+  if (h == 1) {  // the row is complete: its total
+    const float tj = group_last(rs, lane);
+    if (j == 0) st.t0 = tj;
+    else if (j == 1) st.t1p = tj + st.t0;
+    else if (j == 2) st.t2 = tj;
+  }
+  incl_in_block = inner;
+  return st.carry + inner;
+}
+
+template <int F, bool POW2>
+__global__ __launch_bounds__(F2N_BLOCK) void density_march8_kernel(
+  const float * __restrict__ rays_o, const float * __restrict__ rays_d,
+  const float * __restrict__ noise, const uint16_t * __restrict__ table,
+  const int32_t * __restrict__ primes, const float * __restrict__ bias,
+  const float * __restrict__ mul, const float * __restrict__ w0, const float * __restrict__ b0,
+  int32_t * __restrict__ kept, int n_rays, int S, float step, int L, uint32_t T,
+  int64_t level_stride, float t_thresh, float density_shift)
+{
+  const int lane = lane_id(), g = lane >> 3, m = lane & 7;
+  const int r_raw = (ray_of_wave() << 3) + g;
+  const bool has_ray = r_raw < n_rays;
+  const int r = has_ray ? r_raw : n_rays - 1;  // (the spare groups of the last wave redo the last ray)
+  const RayFrame rf = load_ray(rays_o, rays_d, r);
+  const float * nrow = noise ? noise + (int64_t)r * S : nullptr;
+  const float bias0 = b0[0];
+  HalfScan ns = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ds = ns;
+  float lx = 0.f, ly = 0.f, lz = 0.f;  // last sample point of the previous stride
+  int n_kept = 0;
+  bool done = !has_ray;
+  for (int k0 = 0; k0 < S; k0 += 8) {
+    const int j = (k0 >> 4) & 3, h = (k0 >> 3) & 1;
+    const int k = k0 + m;
+    const bool valid = k < S;
+    float cum, dummy;
+    if (nrow) {
+      const float nz = valid ? nrow[k] : 0.f;
+      cum = half_scan_step(nz, j, h, m, lane, ns, dummy);
+      if (j == 3 && h == 1) ns.carry = ns.carry + group_last(dummy, lane);  // (T3 + T2) + (T1 + T0)
+    } else {
+      cum = (float)(min(k, S - 1) + 1);
+    }
+    const float t = cum * step;
+    const float mx = rf.dx * t, my = rf.dy * t, mz = rf.dz * t;
+    const float px = rf.ox + mx, py = rf.oy + my, pz = rf.oz + mz;
+    const float sx = dpp_get<0x111, 0xf, 0xf>(px, 0.f), sy = dpp_get<0x111, 0xf, 0xf>(py, 0.f),
+                sz = dpp_get<0x111, 0xf, 0xf>(pz, 0.f);  // (moved by all lanes, then selected)
+    const float qx = m >= 1 ? sx : lx, qy = m >= 1 ? sy : ly, qz = m >= 1 ? sz : lz;
+    const float ex = px - qx, ey = py - qy, ez = pz - qz;
+    const float dt = (k == 0) ? 0.f : sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+    lx = group_last(px, lane);
+    ly = group_last(py, lane);
+    lz = group_last(pz, lane);
+    float x = px, y = py, z = pz;
+    contract_point(x, y, z);
+    float logit = bias0;
+    for (int l = 0; l < L; l++) {
+      const LevelParams lp = load_level(primes, bias, mul, l);
+      uint32_t row[8];
+      float w[8], acc[F];
+      corner_rows_and_weights<POW2>(x, y, z, lp, T, row, w);
+      gather_blend<F>(table + level_stride * l, row, w, acc);
+#pragma unroll
+      for (int kk = 0; kk < F; kk++) logit = fmaf(round_f16(acc[kk]), w0[l * F + kk], logit);
+    }
+    const float sigma = expf(logit - density_shift);
+    const float sec = valid ? sigma * dt : 0.f;
+    float incl;
+    half_scan_step(sec, j, h, m, lane, ds, incl);
+    const float before = (j == 0 && h == 0) ? 0.f : ds.last;
+    const float shifted = dpp_get<0x111, 0xf, 0xf>(incl, 0.f);
+    const float prev = m >= 1 ? shifted : before;
+    const float depth = ds.carry + prev;
+    ds.last = group_last(incl, lane);
+    if (j == 3 && h == 1) ds.carry = ds.carry + ds.last;
+    const float trans = expf(-depth);
+    const bool keep = valid && !done && (trans > t_thresh);
+    const unsigned long long mk = __ballot(keep);
+    const int cnt = __popc((uint32_t)(mk >> (8 * g)) & 0xffu);
+    if (!done) {
+      n_kept += cnt;
+      if (cnt < min(8, S - k0)) done = true;  // the mask is a prefix: nothing later survives
+    }
+    if (__ballot(!done) == 0ull) break;
+  }
+  if (has_ray && m == 0) kept[r_raw] = n_kept;
+}
+
 // ---- f2n_density_scan ---------------------------------------------------------------------------
 // The keep-prefix of every ray from an ALREADY COMPUTED encoding of all its samples (channel-major
 // [C, n_all]): same logit FMA chain, same scan and same threshold test as density_march_kernel, so
@@ -479,6 +628,72 @@ __global__ __launch_bounds__(kScanBlock) void bounds_from_counts_kernel(
   if (tid == 0 && total) total[0] = carry;
 }
 
+// Up to 2^17 rays: one workgroup per 1024 rays.  Each re-derives its own offset -- the sum of all
+// counts before its rays, read straight from `kept` (256 KiB for 65 536 rays: L2-resident; 8 MB of L2
+// reads over all workgroups) -- so there is neither a second launch nor a hand-off between
+// workgroups, and the 0.75 MB of loads and stores no longer pass through one CU (65 536 rays:
+// 42 -> ~6 us).  Integer sums: the same bounds whatever the order.
+constexpr int kMultiScanBlock = 256, kMultiScanItems = 4;
+constexpr int kMultiScanRays = kMultiScanBlock * kMultiScanItems;
+constexpr int kMultiScanMaxRays = 1 << 17;
+
+__global__ __launch_bounds__(kMultiScanBlock) void bounds_from_counts_multi_kernel(
+  const int32_t * __restrict__ kept, int32_t * __restrict__ bounds, int32_t * __restrict__ total,
+  int n_rays)
+{
+  constexpr int kWaves = kMultiScanBlock / F2N_WAVE;
+  __shared__ int wave_part[kWaves], wave_tot[kWaves];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int first = (int)blockIdx.x * kMultiScanRays;  // (a multiple of 1024: int4 loads stay aligned)
+  const bool vec = (reinterpret_cast<uintptr_t>(kept) & 15u) == 0;
+  // ---- everything before this workgroup's rays
+  int before = 0;
+  if (vec) {
+    for (int i = 4 * tid; i < first; i += 4 * kMultiScanBlock) {
+      const int4 q = *reinterpret_cast<const int4 *>(kept + i);
+      before += (q.x + q.y) + (q.z + q.w);
+    }
+  } else {
+    for (int i = tid; i < first; i += kMultiScanBlock) before += kept[i];
+  }
+  before = __builtin_amdgcn_readlane(wave_incl_scan_i32(before), 63);
+  // ---- this workgroup's rays
+  const int i0 = first + tid * kMultiScanItems;
+  int v[kMultiScanItems];
+  int local = 0;
+#pragma unroll
+  for (int j = 0; j < kMultiScanItems; j++) {
+    v[j] = (i0 + j < n_rays) ? kept[i0 + j] : 0;
+    local += v[j];
+  }
+  const int incl = wave_incl_scan_i32(local);
+  if (lane == 63) wave_tot[wv] = incl;
+  if (lane == 0) wave_part[wv] = before;
+  __syncthreads();
+  int offset = 0, lower = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    offset += wave_part[w];
+    if (w < wv) lower += wave_tot[w];
+    all += wave_tot[w];
+  }
+  int run = offset + lower + (incl - local);
+  const bool pair_aligned = (reinterpret_cast<uintptr_t>(bounds) & 7u) == 0;
+#pragma unroll
+  for (int j = 0; j < kMultiScanItems; j++) {
+    if (i0 + j < n_rays) {
+      if (pair_aligned) {
+        *reinterpret_cast<int2 *>(bounds + 2 * (i0 + j)) = make_int2(run, run + v[j]);
+      } else {
+        bounds[2 * (i0 + j)] = run;
+        bounds[2 * (i0 + j) + 1] = run + v[j];
+      }
+    }
+    run += v[j];
+  }
+  if (total && blockIdx.x == gridDim.x - 1 && tid == 0) total[0] = offset + all;
+}
+
 inline bool is_pow2(uint32_t v) { return v && !(v & (v - 1u)); }
 
 }  // namespace
@@ -524,13 +739,21 @@ extern "C" int f2n_density_march(
   if (!rays_o || !rays_d || !table_f16 || !primes || !bias || !mul || !w0 || !b0 || !kept)
     return F2N_E_INVALID_ARG;
   if (reinterpret_cast<uintptr_t>(table_f16) % (2u * F)) return F2N_E_INVALID_ARG;
-  // four rays per wavefront (16-sample strides) unless F2N_OPT_MARCH = 1 asks for one (64)
-  const bool rows = f2n_get_option(F2N_OPT_MARCH) == 0;
-  const dim3 grid(f2n_div_up(n_rays, F2N_WAVES_PER_BLOCK * (rows ? 4 : 1))), block(F2N_BLOCK);
+  // eight rays per wavefront (8-sample strides) unless F2N_OPT_MARCH asks for one (1: 64-sample
+  // strides, round 2) or four (2: 16-sample strides)
+  const int route = f2n_get_option(F2N_OPT_MARCH);
+  const bool rows = route == 2;
+  const int rays_per_wave = route == 1 ? 1 : route == 2 ? 4 : 8;
+  const dim3 grid(f2n_div_up(n_rays, F2N_WAVES_PER_BLOCK * rays_per_wave)), block(F2N_BLOCK);
   hipStream_t s = (hipStream_t)stream;
   const bool p2 = is_pow2(T);
 #define F2N_MARCH(FF, P2)                                                                         \
-  if (rows)                                                                                       \
+  if (route == 0)                                                                                 \
+    hipLaunchKernelGGL(                                                                           \
+      (density_march8_kernel<FF, P2>), grid, block, 0, s, rays_o, rays_d, noise, table_f16,       \
+      primes, bias, mul, w0, b0, kept, n_rays, S, step, L, T, level_stride, t_thresh,             \
+      density_shift);                                                                             \
+  else if (rows)                                                                                  \
     hipLaunchKernelGGL(                                                                           \
       (density_march16_kernel<FF, P2>), grid, block, 0, s, rays_o, rays_d, noise, table_f16,      \
       primes, bias, mul, w0, b0, kept, n_rays, S, step, L, T, level_stride, t_thresh,             \
@@ -606,8 +829,13 @@ extern "C" int f2n_bounds_from_counts(
 {
   if (n_rays < 0 || n_rays > (1 << 24)) return F2N_E_INVALID_ARG;
   if (n_rays > 0 && (!kept || !bounds)) return F2N_E_INVALID_ARG;
-  hipLaunchKernelGGL(
-    bounds_from_counts_kernel, dim3(1), dim3(kScanBlock), 0, (hipStream_t)stream, kept, bounds,
-    total, n_rays);
+  if (n_rays > kMultiScanRays && n_rays <= kMultiScanMaxRays)
+    hipLaunchKernelGGL(
+      bounds_from_counts_multi_kernel, dim3(f2n_div_up(n_rays, kMultiScanRays)),
+      dim3(kMultiScanBlock), 0, (hipStream_t)stream, kept, bounds, total, n_rays);
+  else
+    hipLaunchKernelGGL(
+      bounds_from_counts_kernel, dim3(1), dim3(kScanBlock), 0, (hipStream_t)stream, kept, bounds,
+      total, n_rays);
   return f2n_launch_status();
 }

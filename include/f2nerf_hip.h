@@ -56,8 +56,9 @@ const char * f2n_status_string(int status);
 #define F2N_OPT_BWD_COMBINE 5   /* binned backward: 0 combine coarse levels per tile, 1 never       */
 #define F2N_OPT_RAYTILE_WALK 6  /* lanes of f2n_hash_fwd_raytile: 0 chosen per tile, 1 across rays at one
                                    sample index, 2 along a ray, 3 across rays in depth order        */
-#define F2N_OPT_MARCH 7         /* f2n_density_march: 0 four rays per wavefront in strides of 16 samples,
-                                  1 one ray per wavefront in strides of 64 (round 2); same counts   */
+#define F2N_OPT_MARCH 7         /* f2n_density_march: 0 eight rays per wavefront in strides of 8 samples,
+                                  1 one ray per wavefront in strides of 64 (round 2), 2 four rays in
+                                  strides of 16; same counts                                          */
 #define F2N_OPT_COUNT 8
 int f2n_set_option(int key, int value);
 int f2n_get_option(int key);

@@ -62,14 +62,16 @@ def test_density_march_and_compact(capi, dev, L, F, log2_T, S, step, bias0, trai
               field.bias_pool.detach().to(dev), field.mul.to(dev), w0, b0, kept, n_rays, S, step,
               L, F, field.T, field.level_stride, 1e-4, 3.0)
     got = kept.cpu()
-    # the one-ray-per-wavefront march (strides of 64) and the default four-rays-per-wavefront one
-    # (strides of 16) perform the same additions in the same order: identical counts, always
-    kept64 = torch.zeros(n_rays, dtype=torch.int32, device=dev)
-    with capi.option("MARCH", 1):
-        capi.call("density_march", d_o, d_d, d_noise, table16, field.prim_pool.to(dev),
-                  field.bias_pool.detach().to(dev), field.mul.to(dev), w0, b0, kept64, n_rays, S, step,
-                  L, F, field.T, field.level_stride, 1e-4, 3.0)
-    assert torch.equal(kept64.cpu(), got)
+    # the one-ray-per-wavefront march (strides of 64), the four-rays-per-wavefront one (strides of
+    # 16) and the default eight-rays-per-wavefront one (strides of 8) perform the same additions in
+    # the same order: identical counts, always
+    for route in (1, 2):
+        kept_r = torch.zeros(n_rays, dtype=torch.int32, device=dev)
+        with capi.option("MARCH", route):
+            capi.call("density_march", d_o, d_d, d_noise, table16, field.prim_pool.to(dev),
+                      field.bias_pool.detach().to(dev), field.mul.to(dev), w0, b0, kept_r, n_rays, S,
+                      step, L, F, field.T, field.level_stride, 1e-4, 3.0)
+        assert torch.equal(kept_r.cpu(), got), route
     # T is compared against a threshold: a ray whose T sits within rounding of 1e-4 may keep one
     # sample more or less.  Everything else must agree exactly.
     diff = (got - num).abs()
@@ -98,7 +100,8 @@ def test_density_march_and_compact(capi, dev, L, F, log2_T, S, step, bias0, trai
 
 def test_bounds_from_counts_large(capi, dev):
     g = torch.Generator().manual_seed(0)
-    for n in (1, 63, 4096, 4097, 70001):
+    # (1 .. 1024 and above 2^17 rays: one workgroup; between: one workgroup per 1024 rays)
+    for n in (1, 63, 1024, 1025, 4096, 4097, 65536, 70001, 131072, 131073):
         cnt = torch.randint(0, 1025, (n,), generator=g).to(torch.int32)
         bounds = torch.zeros(n, 2, dtype=torch.int32, device=dev)
         total = torch.zeros(1, dtype=torch.int32, device=dev)
