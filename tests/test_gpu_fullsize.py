@@ -125,6 +125,12 @@ def test_first_pass_kernels_agree_and_composite_conserves(capi, dev, field):
         outs.append((c, dep, w, idx))
     # the early-terminating march and the encode-once dense pass find the same kept prefix
     assert torch.equal(outs[0][3], outs[1][3])
+    # ... and so do the march's older routes (one ray per wavefront, four rays per wavefront)
+    ren.set_dense_first_pass(0)
+    for route in (1, 2):
+        with capi.option("MARCH", route), torch.no_grad():
+            _, _, _, idx_r = ren.render(o, d, emb, "train", noise, bg)
+        assert torch.equal(idx_r, outs[0][3]), route
     assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0])
     c, dep, w, idx = outs[0]
     cnt = (idx[:, 1] - idx[:, 0])
