@@ -674,7 +674,8 @@ __global__ __launch_bounds__(MShape<C>::kWaves * 64) void shade_bwd_mfma_kernel(
 
 // ---- forward on the matrix cores ------------------------------------------------------------------
 // The forward third of the kernel above (head, hidden and output layer in the Q-layout, no lane
-// movement), three waves per SIMD: no accumulators live across strides and the other waves hide one
+// movement), four waves per SIMD (three until the end of round 3; two, three, four: 0.584, 0.577,
+// 0.551 ms per 8.4 M samples alone): no accumulators live across strides and the other waves hide one
 // wave's loads.  The output layer STAYS on the matrix cores here (rows 0, 4, 8 of a 16-row operand):
 // the vector form the backward uses was measured here too and lost, 0.58 against 0.55 ms per 8.2 M
 // samples inside the bench -- 52 products fewer but 200 vector instructions more and, at 168
@@ -689,7 +690,8 @@ struct FShape
   static constexpr int oBh = kSlots * 64, oB1 = oBh + 16, oB2 = oB1 + 64, kWFloats = oB2 + 4;
   static constexpr int kP = 68;             // [16][kP] SH tile per wave (b32 accesses only)
   static constexpr int kWaveFloats = 16 * kP;
-  static constexpr int kWaves = W;   // 12 = three per SIMD (the kernel needs 136 registers), 8 = two
+  static constexpr int kWaves = W;   // 16 = four per SIMD (the default: the allocator fits 128 registers
+                                     // without spilling; 0.552 -> 0.536 ms per 8.2 M samples), 12 = three, 8 = two
   static constexpr int kLdsFloats = kWFloats + kWaves * kWaveFloats;
 };
 
@@ -928,7 +930,8 @@ int launch_shade_fwd_mfma(
 #define F2N_LAUNCH_FWD(CC)                                                   \
   if (wide) F2N_LAUNCH_FWD_W(CC, true, 12)                                   \
   else if (two_per_simd) F2N_LAUNCH_FWD_W(CC, false, 8)                      \
-  else F2N_LAUNCH_FWD_W(CC, false, 12)
+  else if (f2n_get_option(F2N_OPT_SHADE_VARIANT) == 3) F2N_LAUNCH_FWD_W(CC, false, 12) \
+  else F2N_LAUNCH_FWD_W(CC, false, 16)
   switch (C) {
     case 8: F2N_LAUNCH_FWD(8) break;
     case 16: F2N_LAUNCH_FWD(16) break;

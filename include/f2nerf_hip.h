@@ -49,8 +49,8 @@ const char * f2n_status_string(int status);
  * f2n_set_option returns the previous value, or F2N_E_INVALID_ARG for an unknown key / value. */
 #define F2N_OPT_SHADE_FWD 0     /* 0 matrix-core forward, 1 one-sample-per-lane vector kernel       */
 #define F2N_OPT_SHADE_BWD 1     /* 0 matrix-core backward, 1 vector (VALU + LDS) backward           */
-#define F2N_OPT_SHADE_VARIANT 2 /* matrix-core backward: 0 phases may overlap, 1 phase-fenced; 2: the
-                                  matrix-core FORWARD at two waves per SIMD instead of three       */
+#define F2N_OPT_SHADE_VARIANT 2 /* matrix-core backward: 0 phases may overlap, 1 phase-fenced; the
+                                  matrix-core FORWARD: 0 four waves per SIMD, 3 three, 2 two          */
 #define F2N_OPT_RAYTILE 3       /* samples per ray tile of f2n_hash_fwd_raytile: 0 auto, 16, 32     */
 #define F2N_OPT_HASH_BWD 4      /* f2n_hash_bwd route: 0 auto, 1 global atomics, 2 LDS-sliced       */
 #define F2N_OPT_BWD_COMBINE 5   /* binned backward: 0 combine coarse levels per tile, 1 never       */

@@ -69,6 +69,16 @@ def test_shade_fwd_bwd(capi, dev, C, n, with_emb):
         else:   # the hidden pre-activations the two kernels hand to a backward agree
             torch.testing.assert_close(pre_cm, pre_first, rtol=1e-4, atol=1e-5)
     capi.set_option("SHADE_FWD", 0)
+    # the matrix-core forward at two and three waves per SIMD (default: four): the same instruction
+    # stream per wave, so the same bits
+    capi.call("shade_fwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
+              Pd["w2"], Pd["b2"], emb, logit, rgb, pre_cm, n)
+    base = (logit.clone(), rgb.clone(), pre_cm.clone())
+    for variant in (2, 3):
+        with capi.option("SHADE_VARIANT", variant):
+            capi.call("shade_fwd", enc_cm, C, dv(dirs), d_img, Pd["w_h"], Pd["b_h"], Pd["w1"], Pd["b1"],
+                      Pd["w2"], Pd["b2"], emb, logit, rgb, pre_cm, n)
+        assert torch.equal(logit, base[0]) and torch.equal(rgb, base[1]) and torch.equal(pre_cm, base[2]), variant
 
     # three routes to the same gradients: the matrix-core kernel (default where it has a tiling:
     # C in 8/16/32/64), the vector kernel recomputing the forward, and the vector kernel fed with the
