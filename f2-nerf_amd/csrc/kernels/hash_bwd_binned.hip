@@ -1066,14 +1066,14 @@ template <int F, bool DISJOINT>
 __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_kernel(
   const uint32_t * __restrict__ ws_records, const uint32_t * __restrict__ ws_counts,
   float * __restrict__ table_grad, uint32_t T, int64_t level_stride, float inv_scale, int n_slices,
-  int qcap, int64_t n_tiles)
+  int qcap, int64_t n_tiles, int level_first, int level_step)
 {
   constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
   constexpr uint32_t kRows = kBinAcc / F;
   constexpr int kWaves = kBinBlock / 64;
   __shared__ SliceAcc acc;
   __shared__ uint32_t batch_off[kWaves][64 + 1];
-  const int sidx = blockIdx.x, l = blockIdx.y;
+  const int sidx = blockIdx.x, l = level_first + (int)blockIdx.y * level_step;
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
   const uint32_t row_lo = (uint32_t)sidx * kRows;
@@ -1164,14 +1164,14 @@ template <int F, bool DISJOINT>
 __global__ __launch_bounds__(kBinBlock) void hash_bwd_reduce_runs_kernel(
   const uint32_t * __restrict__ b_records, const uint32_t * __restrict__ b_counts,
   float * __restrict__ table_grad, uint32_t T, int64_t level_stride, float inv_scale, int n_slices,
-  int n_parts, int cap2, int log2_sub, const Arena arena)
+  int n_parts, int cap2, int log2_sub, const Arena arena, int level_first, int level_step)
 {
   constexpr int KW = Rec<F>::kWords, VW = Rec<F>::kValWords;
   constexpr uint32_t kRows = kBinAcc / F;
   constexpr int kWaves = kBinBlock / 64;
   constexpr int kUnroll = 8;
   __shared__ SliceAcc acc;
-  const int sidx = blockIdx.x, l = blockIdx.y;
+  const int sidx = blockIdx.x, l = level_first + (int)blockIdx.y * level_step;
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
   const uint32_t row_lo = (uint32_t)sidx * kRows;
@@ -1400,8 +1400,21 @@ extern "C" int f2n_hash_bwd_binned(
   const bool p2 = is_pow2(T);
   const float inv = 1.f / grad_scale;
   const int combine = f2n_get_option(F2N_OPT_BWD_COMBINE) == 0 ? 1 : 0;
-  // level windows [stride*l, stride*l + T*F) do not overlap: a slice owns its elements alone
+  // Level windows [stride*l, stride*l + T*F): where they do not overlap a slice owns its elements
+  // alone and adds with a plain read-modify-write.  Where they do (the reference's layout: stride = T,
+  // windows of 2 T elements at F = 2, quirk Q2) the slices of two levels share elements and add with
+  // float atomics: into a zeroed gradient that is still order-independent (0 + a + b), into an
+  // existing one (a view rendered in chunks, accumulated in place) the last bit of a shared element
+  // depends on which level came first.  F2N_OPT_BWD_PHASES = 1 removes that: levels l, l + k, l + 2k,
+  // ... do not overlap for k = ceil(T F / stride), so the reduce pass runs in k launches of plain
+  // read-modify-writes -- bit-reproducible, 4 % slower on 8.4 M samples and 25 % on 1 M (half the
+  // workgroups per launch).  More than 8 phases or a stride of 0: atomics either way.
   const bool disjoint = L == 1 || level_stride >= (int64_t)T * F;
+  int phases = disjoint ? 1 : 0;  // 0: float atomics
+  if (!disjoint && f2n_get_option(F2N_OPT_BWD_PHASES) == 1) {
+    const int64_t k = level_stride > 0 ? ((int64_t)T * F + level_stride - 1) / level_stride : 0;
+    if (k >= 2 && k <= 8) phases = (int)k;
+  }
   const int64_t total_tiles = (n + kBinBlock - 1) / kBinBlock;
 
   for (int64_t tile0 = 0; tile0 < total_tiles; tile0 += pl.chunk_tiles) {
@@ -1463,15 +1476,19 @@ extern "C" int f2n_hash_bwd_binned(
         else F2N_BIN_LAUNCH(false, false);
       }
       if (pl.log2_sub == 0) {
-        const dim3 grid_c((unsigned)pl.n_slices, (unsigned)L);
-        if (disjoint)
-          hipLaunchKernelGGL(
-            (hash_bwd_reduce_kernel<FF, true>), grid_c, dim3(kBinBlock), 0, s, a_records, a_counts,
-            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g);
-        else
+        if (phases > 0) {
+          for (int ph = 0; ph < phases && ph < L; ph++) {
+            const dim3 grid_c((unsigned)pl.n_slices, (unsigned)((L - ph + phases - 1) / phases));
+            hipLaunchKernelGGL(
+              (hash_bwd_reduce_kernel<FF, true>), grid_c, dim3(kBinBlock), 0, s, a_records, a_counts,
+              table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g, ph, phases);
+          }
+        } else {
+          const dim3 grid_c((unsigned)pl.n_slices, (unsigned)L);
           hipLaunchKernelGGL(
             (hash_bwd_reduce_kernel<FF, false>), grid_c, dim3(kBinBlock), 0, s, a_records, a_counts,
-            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g);
+            table_grad, T, level_stride, inv, pl.n_slices, pl.qcap, tiles_g, 0, 1);
+        }
       } else {
         SplitArgs sa;
         sa.a_records = a_records;
@@ -1495,17 +1512,21 @@ extern "C" int f2n_hash_bwd_binned(
         sa.arena = arena;
         const dim3 grid_b((unsigned)pl.n_buckets, (unsigned)L, (unsigned)pl.n_parts);
         hipLaunchKernelGGL((hash_bwd_split_kernel<FF>), grid_b, dim3(kSplitBlock), 0, s, sa);
-        const dim3 grid_c((unsigned)pl.n_slices, (unsigned)L);
-        if (disjoint)
-          hipLaunchKernelGGL(
-            (hash_bwd_reduce_runs_kernel<FF, true>), grid_c, dim3(kBinBlock), 0, s, b_records,
-            b_counts, table_grad, T, level_stride, inv, pl.n_slices, pl.n_parts, pl.cap2,
-            pl.log2_sub, arena);
-        else
+        if (phases > 0) {
+          for (int ph = 0; ph < phases && ph < L; ph++) {
+            const dim3 grid_c((unsigned)pl.n_slices, (unsigned)((L - ph + phases - 1) / phases));
+            hipLaunchKernelGGL(
+              (hash_bwd_reduce_runs_kernel<FF, true>), grid_c, dim3(kBinBlock), 0, s, b_records,
+              b_counts, table_grad, T, level_stride, inv, pl.n_slices, pl.n_parts, pl.cap2,
+              pl.log2_sub, arena, ph, phases);
+          }
+        } else {
+          const dim3 grid_c((unsigned)pl.n_slices, (unsigned)L);
           hipLaunchKernelGGL(
             (hash_bwd_reduce_runs_kernel<FF, false>), grid_c, dim3(kBinBlock), 0, s, b_records,
             b_counts, table_grad, T, level_stride, inv, pl.n_slices, pl.n_parts, pl.cap2,
-            pl.log2_sub, arena);
+            pl.log2_sub, arena, 0, 1);
+        }
       }
     })
 #undef F2N_BIN_LAUNCH

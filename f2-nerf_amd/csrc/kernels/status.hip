@@ -12,7 +12,8 @@ bool option_value_ok(int key, int value)
   switch (key) {
     case F2N_OPT_SHADE_FWD:
     case F2N_OPT_SHADE_BWD:
-    case F2N_OPT_BWD_COMBINE: return value == 0 || value == 1;
+    case F2N_OPT_BWD_COMBINE:
+    case F2N_OPT_BWD_PHASES: return value == 0 || value == 1;
     case F2N_OPT_MARCH: return value >= 0 && value <= 2;
     case F2N_OPT_SHADE_VARIANT: return value >= 0 && value <= 3;
     case F2N_OPT_RAYTILE: return value == 0 || value == 16 || value == 32;

@@ -59,7 +59,12 @@ const char * f2n_status_string(int status);
 #define F2N_OPT_MARCH 7         /* f2n_density_march: 0 eight rays per wavefront in strides of 8 samples,
                                   1 one ray per wavefront in strides of 64 (round 2), 2 four rays in
                                   strides of 16; same counts                                          */
-#define F2N_OPT_COUNT 8
+#define F2N_OPT_BWD_PHASES 8    /* binned backward, overlapping level windows (level_stride < T*F): 0 the
+                                  slices of levels that share elements add with float atomics, 1 the
+                                  reduce pass runs in ceil(T*F / level_stride) launches of levels that
+                                  do not overlap: bit-reproducible also when accumulating into an
+                                  existing gradient, 4-25 % slower                                   */
+#define F2N_OPT_COUNT 9
 int f2n_set_option(int key, int value);
 int f2n_get_option(int key);
 
